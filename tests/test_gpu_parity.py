@@ -1,0 +1,308 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the committed goldens.
+
+Bars (BASELINE.json north_star / SURVEY 8(c)):
+  * Perlin: integer hash AND fp64 value bit-exact.
+  * wavelet point lists, textures, WN_GRID_EXACT grids, tile generation: bit-exact.
+  * default (separable brick) dense wavelet grids: |gpu - oracle| <= 1e-5 absolute.
+"""
+import hashlib
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, bits, raw
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north_star: "within 1e-5 abs of the reference float WNoise"
+
+
+@pytest.fixture(scope="module")
+def wn():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (the product has no CPU path)"
+    return importlib.import_module("wavelet-noise-in-ray-tracing_amd")
+
+
+@pytest.fixture(scope="module")
+def noise3(wn):
+    n = wn.WaveletNoise(128, 12345)
+    n.generateNoiseTile3D()
+    return n
+
+
+@pytest.fixture(scope="module")
+def noise2(wn):
+    n = wn.WaveletNoise(128, 12345)
+    n.generateNoiseTile2D()
+    return n
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ---- tile generation (device filter passes) -------------------------------------------------------
+def test_tile_generation_bit_exact(wn, noise2, noise3, tile2d_128, tile3d_128, artefacts):
+    assert (bits(noise2.getNoiseCoefficients()) == bits(tile2d_128)).all()
+    c3 = noise3.getNoiseCoefficients()
+    assert (bits(c3) == bits(tile3d_128)).all()
+    assert hashlib.sha256(c3.tobytes()).hexdigest() == artefacts["tile3d_128_12345"]["sha256"]
+
+
+def test_tile_generation_small_odd_and_repeated(wn, gold, ora):
+    for n, seed, dims, key in ((8, 7, 3, "tile3d_8_7"), (16, 12345, 3, "tile3d_16_12345"),
+                               (16, 99, 2, "tile2d_16_99"), (7, 3, 2, "tile2d_7odd_3"),
+                               (5, 11, 3, "tile3d_5odd_11")):
+        w = wn.WaveletNoise(n, seed)
+        (w.generateNoiseTile2D if dims == 2 else w.generateNoiseTile3D)()
+        assert (bits(w.getNoiseCoefficients()) == bits(gold[key])).all(), key
+        assert w.getTileSize() == n + (n % 2)
+    # the rng is a member: a second generate continues the stream (WaveletNoise.h:47)
+    R = ora.ref()
+    if R is not None:
+        h = R.ref_wn_new(16, 5)
+        R.ref_wn_generate2d(h)
+        R.ref_wn_generate3d(h)
+        want = np.zeros(R.ref_wn_coeff_count(h), np.float32)
+        R.ref_wn_coeffs(h, want)
+        w = wn.WaveletNoise(16, 5)
+        w.generateNoiseTile2D()
+        w.generateNoiseTile3D()
+        assert (bits(w.getNoiseCoefficients()) == bits(want)).all()
+
+
+# ---- point lists --------------------------------------------------------------------------------------
+def test_points_bit_exact_vs_reference_vectors(wn, gold, noise2, noise3):
+    pts = gold["probe_pts"]
+    assert (bits(host(noise3.evaluate3D(pts))) == bits(gold["probe_e3d"])).all()
+    assert (bits(host(noise2.evaluate2D(pts[:, :2]))) == bits(gold["probe_e2d"])).all()
+    got = noise3.evaluate3DProjected(gold["probe_proj_pts"], gold["probe_proj_normals"])
+    assert (bits(host(got)) == bits(gold["probe_e3dp"])).all()
+
+
+def test_points_small_tiles_wrap(wn, gold):
+    sp = gold["small_pts"]
+    for key, dims in (("tile3d_8_7", 3), ("tile3d_16_12345", 3)):
+        w = wn.WaveletNoise.from_coefficients(gold[key], dims)
+        assert (bits(host(w.evaluate3D(sp))) == bits(gold[key + "_e3d"])).all()
+    w = wn.WaveletNoise.from_coefficients(gold["tile2d_16_99"], 2)
+    assert (bits(host(w.evaluate2D(sp[:, :2]))) == bits(gold["tile2d_16_99_e2d"])).all()
+    # a non power-of-two tile (n = 6) exercises the generic modulo
+    w6 = wn.WaveletNoise.from_coefficients(gold["tile3d_5odd_11"], 3)
+    import oracle
+    assert (bits(host(w6.evaluate3D(sp))) == bits(oracle.evaluate3d(gold["tile3d_5odd_11"], sp))).all()
+
+
+def test_scalar_api_and_empty_tile(wn, noise3, ora, tile3d_128):
+    p = [1.25, -3.75, 100.1]
+    assert noise3.evaluate3D(p) == pytest.approx(0.355737954, abs=2e-7)
+    assert np.float32(noise3.evaluate3D(p)) == ora.evaluate3d(tile3d_128, [p])[0]
+    empty = wn.WaveletNoise(128, 1)  # never generated
+    assert empty.evaluate3D(p) == 0.0 and empty.evaluate2D(p[:2]) == 0.0
+    assert empty.evaluate3DProjected(p, [0, 0, 1]) == 0.0
+    assert empty.getNoiseCoefficients().size == 0
+    # zero points is a no-op
+    assert noise3.evaluate3D(np.zeros((0, 3), np.float32)).numel() == 0
+
+
+def test_large_random_point_list_vs_oracle(wn, noise3, ora, tile3d_128):
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-320, 320, (20000, 3)).astype(np.float32)
+    got = host(noise3.evaluate3D(pts))
+    R = ora.ref()
+    if R is not None:
+        h = R.ref_wn_new(128, 12345)
+        R.ref_wn_generate3d(h)
+        want = np.zeros(len(pts), np.float32)
+        R.ref_wn_eval3d(h, np.ascontiguousarray(pts), len(pts), want)
+    else:
+        want = ora.evaluate3d(tile3d_128, pts[:4000])
+        got = got[:4000]
+    assert (bits(got) == bits(want)).all()
+
+
+# ---- dense grids: the committed raws ---------------------------------------------------------------------
+@pytest.mark.parametrize("octave", (3, 4, 5))
+def test_committed_raw_grids(wn, noise2, noise3, octave):
+    sha = json.load(open(os.path.join(GOLD, "artefacts.json")))["raw"]
+    per = wn.PerlinNoise(12345)
+
+    def digest(t):
+        return hashlib.sha256(host(t).astype("<f4").tobytes()).hexdigest()
+
+    # bit-exact paths: byte-identical files
+    assert digest(wn.generate2DOctaveBandNoise(256, octave, None, noise2)) == sha[f"wavelet_noise_2D_octave_{octave}.raw"]
+    assert digest(wn.generate3DProjectedOctaveBandNoise(256, octave, None, noise3)) == sha[f"wavelet_noise_3Dprojected_octave_{octave}.raw"]
+    assert digest(wn.generatePerlinNoise2D(256, octave, None, per)) == sha[f"perlin_noise_2D_octave_{octave}.raw"]
+    assert digest(wn.generatePerlinNoise3DSliced(256, octave, None, per)) == sha[f"perlin_noise_3Dsliced_octave_{octave}.raw"]
+    exact = wn.generate3DSlicedOctaveBandNoise(256, octave, None, noise3, flags=wn.WN_GRID_EXACT)
+    assert digest(exact) == sha[f"wavelet_noise_3Dsliced_octave_{octave}.raw"]
+    # default path (separable bricks when the lattice step allows): within tolerance
+    fast = host(wn.generate3DSlicedOctaveBandNoise(256, octave, None, noise3)).ravel()
+    want = raw(f"wavelet_noise_3Dsliced_octave_{octave}.raw")
+    assert np.abs(fast - want).max() <= TOL
+
+
+def test_raw_writer_round_trip(wn, noise2, tmp_path):
+    f = tmp_path / "w2d.raw"
+    wn.generate2DOctaveBandNoise(256, 4, str(f), noise2)
+    assert hashlib.sha256(f.read_bytes()).hexdigest() == \
+        json.load(open(os.path.join(GOLD, "artefacts.json")))["raw"]["wavelet_noise_2D_octave_4.raw"]
+
+
+# ---- dense volumes (config 2 / 5 mapping) -------------------------------------------------------------------
+def test_volume_goldens(wn, gold, artefacts, noise3):
+    for name, den, nx, ny, z0, z1, octave in artefacts["volumes"]:
+        want = gold[name]
+        exact = host(wn.wavelet_volume(noise3, den, nx, ny, z0, z1, octave, exact=True))
+        assert (bits(exact) == bits(want)).all(), name
+        fast = host(wn.wavelet_volume(noise3, den, nx, ny, z0, z1, octave))
+        assert np.abs(fast - want).max() <= TOL, name
+
+
+@pytest.mark.parametrize("den,nx,ny,z0,z1,octave", [
+    (512, 512, 24, 0, 8, 4),        # config-2 step .25, full-width rows
+    (512, 512, 9, 505, 512, 4),     # last planes, ragged y
+    (512, 300, 17, 3, 6, 4),        # nx not a multiple of 256; thin slab (BZ=4)
+    (512, 131, 5, 7, 8, 4),         # nx not a multiple of 4 -> scalar stores; one plane
+    (2048, 2048, 8, 1000, 1009, 4), # config-5 step 1/16, 9 planes
+    (1024, 515, 20, 0, 2, 4),       # step 1/8
+    (256, 256, 16, 0, 16, 3),       # step .25 at octave 3
+    (512, 512, 8, 4096, 4104, 4),   # z beyond one tile period (weak-scaling shards)
+    (768, 768, 8, 0, 8, 4),         # non power-of-two divisor, step 1/6
+    (1000, 1000, 8, 0, 8, 4),       # inexact float division in the lattice coordinate
+])
+def test_brick_path_vs_oracle(wn, ora, noise3, tile3d_128, den, nx, ny, z0, z1, octave):
+    want = ora.grid_wavelet3d_volume(tile3d_128, den, nx, ny, z0, z1, octave)
+    fast = host(wn.wavelet_volume(noise3, den, nx, ny, z0, z1, octave))
+    assert fast.shape == want.shape
+    err = np.abs(fast - want).max()
+    assert err <= TOL, err
+    exact = host(wn.wavelet_volume(noise3, den, nx, ny, z0, z1, octave, exact=True))
+    assert (bits(exact) == bits(want)).all()
+
+
+def test_brick_path_small_tiles_and_wrap(wn, ora, gold):
+    """Periodic wrap inside the coefficient box: tiles far smaller than a brick's footprint."""
+    for key in ("tile3d_8_7", "tile3d_16_12345", "tile3d_5odd_11"):
+        coef = gold[key]
+        w = wn.WaveletNoise.from_coefficients(coef, 3)
+        want = ora.grid_wavelet3d_volume(coef, 512, 512, 10, 0, 5, 4)
+        fast = host(wn.wavelet_volume(w, 512, 512, 10, 0, 5, 4))
+        assert np.abs(fast - want).max() <= TOL, key
+
+
+def test_empty_grids_and_empty_tile(wn, noise3):
+    assert wn.wavelet_volume(noise3, 64, 0, 8, 0, 4, 4).numel() == 0
+    assert wn.wavelet_volume(noise3, 64, 8, 8, 4, 4, 4).numel() == 0
+    empty = wn.WaveletNoise(128, 1)
+    v = host(wn.wavelet_volume(empty, 512, 512, 8, 0, 4, 4))
+    assert (v == 0).all()  # empty tile -> 0.0f * inv_stddev
+
+
+# ---- multiband / turb (config 3) -------------------------------------------------------------------------------
+def test_multiband_grid_and_points(wn, ora, noise3, tile3d_128):
+    w = [1.0, 1.0, 1.0, 1.0, 1.0]
+    want = ora.grid_multiband3d_volume(tile3d_128, 512, 512, 8, 16, 20, -16.0, 0, 5, w, 0.18402)
+    fast = host(wn.multiband_volume(noise3, 512, 512, 8, 16, 20, -16.0, 0, 5, w))
+    assert np.abs(fast - want).max() <= TOL
+    exact = host(wn.multiband_volume(noise3, 512, 512, 8, 16, 20, -16.0, 0, 5, w, exact=True))
+    assert (bits(exact) == bits(want)).all()
+    # the top band of config 3 is config 2's band
+    w2 = [0.5, 2.0, 1.0]
+    for s, first, nb in ((-16.0, 1, 3), (-2.0, 0, 3), (0.0, 0, 3), (-16.0, -3, 3)):
+        want = ora.grid_multiband3d_volume(tile3d_128, 256, 256, 8, 0, 3, s, first, nb, w2, 0.21)
+        got = host(wn.multiband_volume(noise3, 256, 256, 8, 0, 3, s, first, nb, w2, variance=0.21))
+        assert np.abs(got - want).max() <= TOL, (s, first, nb)
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-4, 4, (3000, 3)).astype(np.float32)
+    got = host(noise3.WMultibandNoise(pts, -16.0, 0, 5, w))
+    assert (bits(got) == bits(ora.multiband3d(tile3d_128, pts, -16.0, 0, 5, w, 0.18402))).all()
+
+
+def test_perlin_points_grids_turb_fractal(wn, ora, gold):
+    pts = gold["perlin_pts"]
+    for seed in (12345, 5489):
+        p = wn.perlin(seed)
+        assert (p.p == gold["perm_tables"][list(gold["perm_seeds"]).index(seed)]).all()  # integer hash table
+        assert (bits(host(p.noise(pts))) == bits(gold[f"perlin_noise_{seed}"])).all()
+        f32 = pts.astype(np.float32)
+        assert (bits(host(p.noise(f32))) == bits(gold[f"perlin_noise_vec3_{seed}"])).all()
+        assert (bits(host(p.fractal_noise(f32))) == bits(gold[f"perlin_fractal_{seed}"])).all()
+    p = wn.perlin(12345)
+    perm = ora.perlin_perm(12345)
+    assert p.noise(1.25, -3.75, 100.1) == -0.20131776773070792
+    assert p.noise(0.5, 0.5) == ora.perlin_noise(perm, [[0.5, 0.5, 0.0]])[0]
+    f32 = pts[:3000].astype(np.float32)
+    assert (bits(host(p.turb(f32, 7))) == bits(ora.perlin_turb(perm, f32, 7))).all()
+    got = host(wn.turb_volume(p, 512, 512, 6, 9, 12, 7))
+    assert (bits(got) == bits(ora.grid_turb_volume(perm, 512, 512, 6, 9, 12, 7))).all()
+    got = host(wn.perlin_volume(p, 100, 100, 7, 2, 5, 4))
+    assert (bits(got) == bits(ora.grid_perlin_volume(perm, 100, 100, 7, 2, 5, 4))).all()
+
+
+# ---- texture adaptor -------------------------------------------------------------------------------------------------
+def test_textures_bit_exact(wn, gold, artefacts):
+    tp = gold["tex_pts"]
+    cache = {}
+    for kind, scale, octave in artefacts["texture_cases"]:
+        key = f"tex_{kind}_s{scale}_o{octave}"
+        if kind == "perlin":
+            tex = wn.noise_texture(scale, octave)
+        else:
+            k = (kind, scale, octave)
+            tex = cache.get(k) or wn.wavelet_texture(scale, octave, kind == "wavelet3d")
+            cache[k] = tex
+        assert (bits(host(tex.grey(tp))) == bits(gold[key])).all(), key
+    # scalar value(u,v,p) returns an equal-channel colour (texture.h:106)
+    tex = wn.wavelet_texture(1.0, 4, True)
+    c = tex.value(0.0, 0.0, tp[0])
+    assert c[0] == c[1] == c[2] == float(gold["tex_wavelet3d_s1.0_o4"][0])
+
+
+@pytest.mark.parametrize("frac", (0.0, 0.07, 0.59, 1.0))
+def test_texture_active_mask_compaction(wn, gold, frac):
+    """Ballot compaction: active hits get the texture value, the rest are left untouched."""
+    rng = np.random.default_rng(int(frac * 100))
+    n = 70001  # not a multiple of 64 or of the per-wave chunk
+    pts = np.stack([rng.uniform(-10, 10, n), np.full(n, -0.5), rng.uniform(-10, 10, n)], 1).astype(np.float32)
+    active = (rng.random(n) < frac).astype(np.uint8)
+    for tex in (wn.wavelet_texture(1.0, 4, True), wn.noise_texture(1.0, 4)):
+        full = host(tex.grey(pts))
+        out = torch.full((n,), -7.0, dtype=torch.float32, device="cuda")
+        masked = host(tex.grey(pts, active=active, out=out))
+        assert (masked[active == 0] == -7.0).all()
+        assert (bits(masked[active == 1]) == bits(full[active == 1])).all()
+
+
+# ---- size-independent properties at BASELINE sizes ---------------------------------------------------------------------
+def test_full_512_cubed_properties(wn, ora, noise3, tile3d_128):
+    """Config 2 at full size: periodicity, slab consistency, statistics and spot checks."""
+    N = 512
+    vol = wn.wavelet_volume(noise3, N, N, N, 0, N, 4)  # 512 MiB on the device
+    assert vol.shape == (N, N, N)
+    # (1) z-slabs computed separately are bit-identical to the full call (shard-safety)
+    part = wn.wavelet_volume(noise3, N, N, N, 200, 208, 4)
+    assert torch.equal(part, vol[200:208])
+    # (2) the lattice spans exactly one tile period: shifting by N samples reproduces the plane
+    wrap = wn.wavelet_volume(noise3, N, N, N, N + 37, N + 38, 4)
+    assert torch.equal(wrap[0], vol[37])
+    # (3) statistics of one band at unit-ish variance (~N(0, 0.77^2), |v| < 4.5)
+    assert abs(float(vol.mean())) < 5e-3
+    assert 0.70 < float(vol.std()) < 0.85
+    assert float(vol.abs().max()) < 4.5
+    # (4) random spot checks against the oracle's scalar evaluate3D
+    rng = np.random.default_rng(11)
+    idx = rng.integers(0, N, (4000, 3))
+    q = (idx.astype(np.float32) / np.float32(N)) * np.float32(4) * np.float32(16) * np.float32(2)
+    want = ora.evaluate3d(tile3d_128, q[:, ::-1].copy()) * (np.float32(1) / np.sqrt(np.float32(0.18402)))
+    got = host(vol[idx[:, 0], idx[:, 1], idx[:, 2]])
+    assert np.abs(got - want).max() <= TOL
+    # (5) the committed 3-D-sliced raw (octave 4) is the z = 2.0 plane: lattice index 8 at N = 512,
+    #     every second sample in x and y
+    plane = host(vol[8, ::2, ::2]).ravel()
+    assert np.abs(plane - raw("wavelet_noise_3Dsliced_octave_4.raw")).max() <= TOL

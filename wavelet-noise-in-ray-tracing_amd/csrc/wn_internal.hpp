@@ -1,0 +1,110 @@
+// wn_internal.hpp -- shared between the C-ABI translation units of libwnoise_hip.so.
+// gfx950 only; compiled with -ffp-contract=off (fused multiply-adds appear only where a kernel
+// asks for them with __builtin_fmaf).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+
+#include "wnoise.h"
+
+struct wn_tile {
+    int n = 0;          // even tile size (0 = empty tile)
+    int dims = 0;       // 2 or 3
+    size_t count = 0;   // n^dims
+    float *dev = nullptr;
+    int device = 0;
+};
+
+struct wn_perm {
+    int host[512];
+    uint8_t *dev = nullptr; // 512 bytes: values 0..255 (perlin.h:35-38)
+    int device = 0;
+};
+
+struct wn_timer {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
+namespace wn {
+
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+int require_device();
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define WN_HIP(call)                                            \
+    do {                                                        \
+        hipError_t _e = (call);                                 \
+        if (_e != hipSuccess) return ::wn::hip_fail(_e, #call); \
+    } while (0)
+
+#define WN_LAUNCH_CHECK(name)                                    \
+    do {                                                         \
+        hipError_t _e = hipGetLastError();                       \
+        if (_e != hipSuccess) return ::wn::hip_fail(_e, name);   \
+    } while (0)
+
+// Grid coordinate arguments shared by all dense-grid kernels (mirror of wn_grid plus the
+// derived slab extent).
+struct GridArgs {
+    int den, nx, ny, z0, nz; // nz = planes in this call
+    float base_range, octave_scale, post_scale;
+    int z_const_mode;
+    float z_const;
+    float out_scale;
+};
+
+int check_grid(const wn_grid *g, bool needs_z, GridArgs *out);
+
+// wn_tilegen.hip: the filter half of generateNoiseTile2D/3D on the device.
+int tilegen_filter(wn_tile *t, const float *field_dev, hipStream_t stream);
+
+} // namespace wn
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+namespace wn {
+
+// Non-negative modulo (WaveletNoise.cpp:31-34); `mask` = n-1 when n is a power of two, else -1.
+__device__ __forceinline__ int dmod(int x, int n, int mask)
+{
+    if (mask >= 0) return x & mask;
+    int m = x % n;
+    return m < 0 ? m + n : m;
+}
+
+// Lattice coordinate of index i (experient/main.cpp:20-26): ((float(i)/den)*range)*octave*post,
+// one float rounding per operation, division IEEE-correct (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt).
+__device__ __forceinline__ float lattice_coord(int i, float den, float range, float oscale,
+                                               float post)
+{
+    float c = ((float)i / den) * range;
+    c = c * oscale;
+    c = c * post;
+    return c;
+}
+
+// Quadratic B-spline weights (WaveletNoise.cpp:194-200).
+__device__ __forceinline__ void bspline(float p, int &mid, float &w0, float &w1, float &w2)
+{
+    const float pm = p - 0.5f;
+    const float cm = ceilf(pm);
+    mid = (int)cm;
+    const float t = cm - pm;
+    w0 = t * t / 2.0f;
+    w2 = (1.0f - t) * (1.0f - t) / 2.0f;
+    w1 = 1.0f - w0 - w2;
+}
+
+} // namespace wn
+#endif

@@ -1,0 +1,586 @@
+// wn_wavelet_grid.hip -- dense-grid wavelet noise for gfx950 (K1/K3/K3p/K5 of SURVEY.md 8).
+//
+// Two kernels stand under wn_eval3d_grid / wn_multiband3d_grid:
+//
+//  * grid3d_sep_kernel<NB>  (default).  A dense lattice is axis-aligned, so the 27-tap sum of
+//    WaveletNoise::evaluate3D (WaveletNoise.cpp:202-213) factors per axis:
+//        out[x,y,z] = sum_i Wx[x,i] * ( sum_j Wy[y,j] * ( sum_k Wz[z,k] * C[i,j,k] ) ).
+//    One workgroup (4 waves) owns a brick of 256 x BY x BZ samples.  It stages the brick's
+//    coefficient box (with the periodic wrap resolved) through LDS, collapses y and z for every
+//    sample row into LDS rows R[row][i] (9 FMAs per coefficient column), then each lane
+//    produces 4 consecutive x samples per row from a 4-wide window of R with its 16 window
+//    weights held in registers, and stores one float4: every wave store is 1 KiB contiguous.
+//    Per-axis weights/mids are computed exactly as the reference does; only the order of the
+//    final sums differs (<= ~1e-6 abs; tolerance 1e-5).  NB > 1 accumulates NB bands in-kernel
+//    (Cook & DeRose WMultibandNoise) with one store.
+//    Bound: HBM write stream, 4 B/sample (+ the 8 MiB tile, read once, L2/MALL resident).
+//
+//  * grid3d_direct_kernel (WN_GRID_EXACT, or lattices the brick scheme does not cover: step
+//    > 1/3 cell per sample, negative steps).  One sample per lane, the reference's loop order
+//    and unfused arithmetic: bit-identical to evaluate3D.
+//
+// 2-D and projected grids use direct kernels (bit-identical to evaluate2D / evaluate3DProjected).
+#include "wn_internal.hpp"
+#include "wn_device_eval.hpp"
+
+#include <cmath>
+
+namespace {
+
+using wn::GridArgs;
+
+constexpr int kMaxBands = 8;
+constexpr int kBrickX = 256;     // samples per brick along x (64 lanes x 4)
+constexpr int kMaxRows = 64;     // BY*BZ
+constexpr int kMaxBY = 16, kMaxBZ = 8;
+
+struct BandArgs {
+    float oscale; // octave_scale of this band
+    float weight; // w[b]
+    int box_off;  // float offset of this band's coefficient box in dynamic LDS
+    int r_off;    // float offset of this band's collapsed rows
+};
+
+struct SepArgs {
+    const float *coef;
+    float *out;
+    int n, nmask;
+    GridArgs g;
+    int by_log2, bz_log2;
+    int nbx, nby, nbz;
+    int nbands;
+    float out_div;
+    int vec4_ok;
+    BandArgs band[kMaxBands];
+};
+
+// Bijective XCD-aware remap: hardware deals consecutive workgroup ids round-robin over the 8
+// XCDs, so ids congruent mod 8 share an L2.  Give each XCD one contiguous range of bricks
+// (contiguous z-range of the volume => 1/8 of the tile per L2).
+__device__ __forceinline__ int xcd_remap(int id, int total)
+{
+    const int q = total >> 3, r = total & 7;
+    const int xcd = id & 7, k = id >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void grid3d_sep_kernel(const SepArgs a)
+{
+    extern __shared__ float lds[];
+    // per-band sample tables: slots 0..15 y samples, 16..23 z samples, 24/25 first/last x
+    __shared__ int s_mid[NB][32];
+    __shared__ float s_w[NB][32][3];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int BY = 1 << a.by_log2, BZ = 1 << a.bz_log2, rows = BY * BZ;
+    const GridArgs &g = a.g;
+    const float den = (float)g.den;
+
+    int brick = xcd_remap(blockIdx.x, a.nbx * a.nby * a.nbz);
+    const int bx = brick % a.nbx;
+    brick /= a.nbx;
+    const int by = brick % a.nby, bz = brick / a.nby;
+    const int x_first = bx * kBrickX, x_last = min(x_first + kBrickX - 1, g.nx - 1);
+
+    // ---- per-band tables --------------------------------------------------------------------
+    {
+        const int b = tid >> 5, slot = tid & 31;
+        if (b < NB) {
+            int idx = 0;
+            bool is_const = false;
+            if (slot < 16) idx = min(by * BY + min(slot, BY - 1), g.ny - 1);
+            else if (slot < 24) {
+                idx = g.z0 + min(bz * BZ + min(slot - 16, BZ - 1), g.nz - 1);
+                is_const = g.z_const_mode != 0;
+            } else idx = (slot == 24) ? x_first : x_last;
+            float c = is_const ? g.z_const
+                               : wn::lattice_coord(idx, den, g.base_range, a.band[b].oscale,
+                                                   g.post_scale);
+            int m;
+            float w0, w1, w2;
+            wn::bspline(c, m, w0, w1, w2);
+            s_mid[b][slot] = m;
+            s_w[b][slot][0] = w0;
+            s_w[b][slot][1] = w1;
+            s_w[b][slot][2] = w2;
+        }
+    }
+
+    // ---- this lane's 4 x samples: window base and 16 window weights per band -------------------
+    const int x0 = x_first + lane * 4;
+    float xbase[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        xbase[q] = ((float)min(x0 + q, g.nx - 1) / den) * g.base_range;
+    float ww[NB][4][4];
+    int wmid0[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        int m[4];
+        float w[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float c = xbase[q] * a.band[b].oscale;
+            c = c * g.post_scale;
+            wn::bspline(c, m[q], w[q][0], w[q][1], w[q][2]);
+        }
+        wmid0[b] = m[0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int d = m[q] - m[0]; // 0 or 1 (host guarantees step <= 1/3)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int tap = c - d;
+                ww[b][q][c] = (tap == 0) ? w[q][0] : (tap == 1) ? w[q][1] : (tap == 2) ? w[q][2] : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 0: coefficient boxes -> LDS (periodic wrap resolved here) -----------------------
+    int ix0[NB], jy0[NB], kz0[NB], EX[NB], EY[NB], EZ[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        ix0[b] = s_mid[b][24] - 1;
+        EX[b] = s_mid[b][25] - s_mid[b][24] + 4; // +3 support, +1 pad column (zero-weight tap)
+        jy0[b] = s_mid[b][0] - 1;
+        EY[b] = s_mid[b][BY - 1] - s_mid[b][0] + 3;
+        kz0[b] = s_mid[b][16] - 1;
+        EZ[b] = s_mid[b][16 + BZ - 1] - s_mid[b][16] + 3;
+        float *box = lds + a.band[b].box_off;
+        const int nrows = EZ[b] * EY[b];
+        for (int r = wave; r < nrows; r += 4) {
+            const int k = r / EY[b], j = r - k * EY[b];
+            const float *src = a.coef + ((size_t)wn::dmod(kz0[b] + k, a.n, a.nmask) * a.n +
+                                         wn::dmod(jy0[b] + j, a.n, a.nmask)) * a.n;
+            for (int i = lane; i < EX[b]; i += 64)
+                box[r * EX[b] + i] = src[wn::dmod(ix0[b] + i, a.n, a.nmask)];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: collapse y and z: R[row][i] = sum_k wz[k] sum_j wy[j] C[k][j][i] --------------
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float *box = lds + a.band[b].box_off;
+        float *R = lds + a.band[b].r_off;
+        const int ex = EX[b], ey = EY[b];
+        const int total = rows * ex;
+        const float inv_ex = 1.0f / (float)ex;
+        for (int e = tid; e < total; e += 256) {
+            const int row = (int)(((float)e + 0.5f) * inv_ex);
+            const int i = e - row * ex;
+            const int yi = row & (BY - 1), zi = row >> a.by_log2;
+            const int jy = s_mid[b][yi] - 1 - jy0[b];
+            const int kz = s_mid[b][16 + zi] - 1 - kz0[b];
+            const float wy0 = s_w[b][yi][0], wy1 = s_w[b][yi][1], wy2 = s_w[b][yi][2];
+            const float *c = box + (kz * ey + jy) * ex + i;
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float *ck = c + k * ey * ex;
+                float t = wy0 * ck[0];
+                t = __builtin_fmaf(wy1, ck[ex], t);
+                t = __builtin_fmaf(wy2, ck[2 * ex], t);
+                acc = __builtin_fmaf(s_w[b][16 + zi][k], t, acc);
+            }
+            R[e] = acc;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: x from a 4-wide window of R, one float4 per lane per row ------------------------
+    const bool lane_in = x0 < g.nx;
+    for (int row = wave; row < rows; row += 4) {
+        const int yi = row & (BY - 1), zi = row >> a.by_log2;
+        const int y = by * BY + yi, z = bz * BZ + zi;
+        if (y >= g.ny || z >= g.nz) continue; // wave-uniform
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float *R = lds + a.band[b].r_off + row * EX[b] + (wmid0[b] - 1 - ix0[b]);
+            const float v0 = R[0], v1 = R[1], v2 = R[2], v3 = R[3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t = ww[b][q][0] * v0;
+                t = __builtin_fmaf(ww[b][q][1], v1, t);
+                t = __builtin_fmaf(ww[b][q][2], v2, t);
+                t = __builtin_fmaf(ww[b][q][3], v3, t);
+                if (NB == 1) acc[q] = t;
+                else acc[q] = __builtin_fmaf(a.band[b].weight, t, acc[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (NB > 1) acc[q] = acc[q] / a.out_div;
+            acc[q] = acc[q] * g.out_scale;
+        }
+        if (!lane_in) continue;
+        float *dst = a.out + ((size_t)z * g.ny + y) * g.nx + x0;
+        if (a.vec4_ok && x0 + 3 < g.nx) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (x0 + q < g.nx) dst[q] = acc[q];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Direct kernels: the reference's loops, one sample per lane, unfused -> bit-identical.
+// ------------------------------------------------------------------------------------------------
+struct DirectArgs {
+    const float *coef;
+    float *out;
+    int n, nmask;
+    GridArgs g;
+    // multiband (nbands == 0: plain evaluate3D)
+    int nbands;
+    float band_scale[kMaxBands]; // 2^(first_band+b)
+    float band_w[kMaxBands];
+    float out_div;
+    int apply_div;
+};
+
+__global__ __launch_bounds__(256) void grid3d_direct_kernel(const DirectArgs a)
+{
+    const GridArgs &g = a.g;
+    const size_t total = (size_t)g.nx * g.ny * g.nz;
+    const float den = (float)g.den;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(e % g.nx);
+        const size_t r = e / g.nx;
+        const int y = (int)(r % g.ny), z = (int)(r / g.ny);
+        float v;
+        if (a.nbands == 0) {
+            const float px = wn::lattice_coord(x, den, g.base_range, g.octave_scale, g.post_scale);
+            const float py = wn::lattice_coord(y, den, g.base_range, g.octave_scale, g.post_scale);
+            const float pz = g.z_const_mode ? g.z_const
+                                            : wn::lattice_coord(g.z0 + z, den, g.base_range,
+                                                                g.octave_scale, g.post_scale);
+            v = wn::eval3d_exact(a.coef, a.n, a.nmask, px, py, pz);
+        } else {
+            const float px = wn::lattice_coord(x, den, g.base_range, g.octave_scale, g.post_scale);
+            const float py = wn::lattice_coord(y, den, g.base_range, g.octave_scale, g.post_scale);
+            const float pz = g.z_const_mode ? g.z_const
+                                            : wn::lattice_coord(g.z0 + z, den, g.base_range,
+                                                                g.octave_scale, g.post_scale);
+            v = 0.0f;
+            for (int b = 0; b < a.nbands; ++b) {
+                const float s = a.band_scale[b];
+                v += a.band_w[b] * wn::eval3d_exact(a.coef, a.n, a.nmask, 2.0f * px * s,
+                                                2.0f * py * s, 2.0f * pz * s);
+            }
+            if (a.apply_div) v /= a.out_div;
+        }
+        a.out[e] = v * g.out_scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void grid2d_direct_kernel(const DirectArgs a)
+{
+    const GridArgs &g = a.g;
+    const size_t total = (size_t)g.nx * g.ny;
+    const float den = (float)g.den;
+    const int n = a.n;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(e % g.nx), y = (int)(e / g.nx);
+        const float px = wn::lattice_coord(x, den, g.base_range, g.octave_scale, g.post_scale);
+        const float py = wn::lattice_coord(y, den, g.base_range, g.octave_scale, g.post_scale);
+        const float result = wn::eval2d_exact(a.coef, n, a.nmask, px, py);
+        a.out[e] = result * g.out_scale;
+    }
+}
+
+} // namespace
+
+namespace {
+
+struct ProjGridArgs {
+    const float *coef;
+    float *out;
+    int n, nmask;
+    GridArgs g;
+    float normal[3];
+};
+
+__global__ __launch_bounds__(256) void grid3d_projected_kernel(const ProjGridArgs a)
+{
+    const GridArgs &g = a.g;
+    const size_t total = (size_t)g.nx * g.ny * g.nz;
+    const float den = (float)g.den;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(e % g.nx);
+        const size_t r = e / g.nx;
+        const int y = (int)(r % g.ny), z = (int)(r / g.ny);
+        float p[3];
+        p[0] = wn::lattice_coord(x, den, g.base_range, g.octave_scale, g.post_scale);
+        p[1] = wn::lattice_coord(y, den, g.base_range, g.octave_scale, g.post_scale);
+        p[2] = g.z_const_mode ? g.z_const
+                              : wn::lattice_coord(g.z0 + z, den, g.base_range, g.octave_scale,
+                                                  g.post_scale);
+        a.out[e] = wn::projected_exact(a.coef, a.n, a.nmask, p, a.normal) * g.out_scale;
+    }
+}
+
+inline int pow2_mask(int n) { return (n > 0 && (n & (n - 1)) == 0) ? n - 1 : -1; }
+
+inline int grid_blocks(size_t total)
+{
+    size_t b = (total + 255) / 256;
+    const size_t cap = 256u * 8u * 4u;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+inline int ceil_pow2(int v)
+{
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// Plan the separable kernel; returns false when the lattice is outside its regime.
+bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *oscale,
+              const float *weights, SepArgs *a, size_t *lds_bytes)
+{
+    if (tile->n == 0 || nbands < 1 || nbands > kMaxBands) return false;
+    if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0) return false;
+    const int BZ = g.nz >= kMaxBZ ? kMaxBZ : ceil_pow2(g.nz);
+    const int BY = (BZ == kMaxBZ) ? kMaxRows / kMaxBZ : kMaxBY;
+    const int rows = BY * BZ;
+    const double zmax = g.z_const_mode ? 0.0 : (double)g.z0 + g.nz;
+    const double imax = fmax(fmax((double)g.nx, (double)g.ny), zmax);
+    size_t off = 0;
+    for (int b = 0; b < nbands; ++b) {
+        const double step = (double)g.base_range * (double)oscale[b] * (double)g.post_scale / g.den;
+        if (!(step >= 0.0) || !std::isfinite(step)) return false;
+        const double pmax = step * imax + fabs((double)g.z_const) + 1.0;
+        if (pmax > 1.0e6) return false; // keep mids far inside int / float-exact range
+        const double slack = pmax * 4.8e-7; // 4 ulp of the largest coordinate
+        if (3.0 * step + slack > 1.0) return false; // 4 consecutive samples span <= 2 mids
+        auto extent = [&](int samples) { return (int)floor((samples - 1) * step + slack) + 1 + 3; };
+        const int ex = extent(kBrickX) + 1, ey = extent(BY), ez = g.z_const_mode ? 3 : extent(BZ);
+        a->band[b].oscale = oscale[b];
+        a->band[b].weight = weights ? weights[b] : 1.0f;
+        a->band[b].box_off = (int)off;
+        off += (size_t)ex * ey * ez;
+        a->band[b].r_off = (int)off;
+        off += (size_t)rows * ex + 4;
+    }
+    *lds_bytes = off * sizeof(float);
+    if (*lds_bytes > 60 * 1024) return false;
+    a->by_log2 = __builtin_ctz(BY);
+    a->bz_log2 = __builtin_ctz(BZ);
+    a->nbx = (g.nx + kBrickX - 1) / kBrickX;
+    a->nby = (g.ny + BY - 1) / BY;
+    a->nbz = (g.nz + BZ - 1) / BZ;
+    const long long blocks = (long long)a->nbx * a->nby * a->nbz;
+    if (blocks > 0x7fffffffLL) return false;
+    a->nbands = nbands;
+    a->coef = tile->dev;
+    a->n = tile->n;
+    a->nmask = pow2_mask(tile->n);
+    a->g = g;
+    return true;
+}
+
+template <int NB>
+void launch_sep(const SepArgs &a, size_t lds, hipStream_t s)
+{
+    hipLaunchKernelGGL(grid3d_sep_kernel<NB>, dim3(a.nbx * a.nby * a.nbz), dim3(256), lds, s, a);
+}
+
+int run_sep(const SepArgs &a, size_t lds, hipStream_t s)
+{
+    switch (a.nbands) {
+    case 1: launch_sep<1>(a, lds, s); break;
+    case 2: launch_sep<2>(a, lds, s); break;
+    case 3: launch_sep<3>(a, lds, s); break;
+    case 4: launch_sep<4>(a, lds, s); break;
+    case 5: launch_sep<5>(a, lds, s); break;
+    case 6: launch_sep<6>(a, lds, s); break;
+    case 7: launch_sep<7>(a, lds, s); break;
+    default: launch_sep<8>(a, lds, s); break;
+    }
+    WN_LAUNCH_CHECK("grid3d_sep_kernel");
+    return WN_OK;
+}
+
+} // namespace
+
+using namespace wn;
+
+extern "C" {
+
+int wn_eval3d_grid(const wn_tile *tile, const wn_grid *grid, float *out_dev, void *stream)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    if (!tile) return fail(WN_ERR_INVALID, "tile is NULL");
+    if (tile->count && tile->dims != 3) return fail(WN_ERR_INVALID, "wn_eval3d_grid needs a 3-D tile");
+    GridArgs g;
+    rc = check_grid(grid, true, &g);
+    if (rc) return rc;
+    const size_t total = (size_t)g.nx * g.ny * g.nz;
+    if (total == 0) return WN_OK;
+    if (!out_dev) return fail(WN_ERR_INVALID, "out_dev is NULL");
+
+    if (!(grid->flags & WN_GRID_EXACT)) {
+        SepArgs a{};
+        size_t lds = 0;
+        const float os = g.octave_scale;
+        if (plan_sep(tile, g, 1, &os, nullptr, &a, &lds)) {
+            a.out = out_dev;
+            a.out_div = 1.0f;
+            a.vec4_ok = (g.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
+            return run_sep(a, lds, as_stream(stream));
+        }
+    }
+    DirectArgs d{};
+    d.coef = tile->dev;
+    d.out = out_dev;
+    d.n = tile->n;
+    d.nmask = pow2_mask(tile->n);
+    d.g = g;
+    d.nbands = 0;
+    hipLaunchKernelGGL(grid3d_direct_kernel, dim3(grid_blocks(total)), dim3(256), 0,
+                       as_stream(stream), d);
+    WN_LAUNCH_CHECK("grid3d_direct_kernel");
+    return WN_OK;
+}
+
+int wn_multiband3d_grid(const wn_tile *tile, const wn_grid *grid, float s, int first_band,
+                        int nbands, const float *w_host, float var_per_band, float *out_dev,
+                        void *stream)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    if (!tile) return fail(WN_ERR_INVALID, "tile is NULL");
+    if (tile->count && tile->dims != 3) return fail(WN_ERR_INVALID, "wn_multiband3d_grid needs a 3-D tile");
+    if (nbands < 0 || nbands > kMaxBands)
+        return fail(WN_ERR_INVALID, "nbands must be in 0..%d (got %d)", kMaxBands, nbands);
+    if (nbands && !w_host) return fail(WN_ERR_INVALID, "w_host is NULL");
+    GridArgs g;
+    rc = check_grid(grid, true, &g);
+    if (rc) return rc;
+    const size_t total = (size_t)g.nx * g.ny * g.nz;
+    if (total == 0) return WN_OK;
+    if (!out_dev) return fail(WN_ERR_INVALID, "out_dev is NULL");
+
+    // Appendix 2: bands run while s + firstBand + b < 0; the variance sums ALL nbands.
+    int active = 0;
+    while (active < nbands && s + (float)first_band + (float)active < 0.0f) ++active;
+    float variance = 0.0f;
+    for (int b = 0; b < nbands; ++b) variance += w_host[b] * w_host[b];
+    const bool apply_div = variance != 0.0f;
+    const float out_div = apply_div ? sqrtf(variance * var_per_band) : 1.0f;
+
+    float bscale[kMaxBands], wts[kMaxBands], oscale[kMaxBands];
+    for (int b = 0; b < active; ++b) {
+        bscale[b] = ldexpf(1.0f, first_band + b);
+        wts[b] = w_host[b];
+        // q = 2*p*2^(first+b): in lattice form octave_scale*2^(first+b), post 2.
+        oscale[b] = g.octave_scale * bscale[b];
+    }
+
+    if (!(grid->flags & WN_GRID_EXACT) && active >= 1 && g.post_scale == 1.0f) {
+        SepArgs a{};
+        size_t lds = 0;
+        GridArgs gb = g;
+        gb.post_scale = 2.0f;
+        if (plan_sep(tile, gb, active, oscale, wts, &a, &lds)) {
+            a.out = out_dev;
+            a.out_div = out_div;
+            a.vec4_ok = (g.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
+            if (active == 1) {
+                // single active band: the NB==1 instantiation ignores weight/out_div; fold them
+                // into out_scale only when that is exact, otherwise use the exact kernel.
+                if (wts[0] == 1.0f && out_div == 1.0f) return run_sep(a, lds, as_stream(stream));
+            } else {
+                return run_sep(a, lds, as_stream(stream));
+            }
+        }
+    }
+    DirectArgs d{};
+    d.coef = tile->dev;
+    d.out = out_dev;
+    d.n = tile->n;
+    d.nmask = pow2_mask(tile->n);
+    d.g = g;
+    d.nbands = active;
+    for (int b = 0; b < active; ++b) {
+        d.band_scale[b] = bscale[b];
+        d.band_w[b] = wts[b];
+    }
+    d.out_div = out_div;
+    d.apply_div = apply_div ? 1 : 0;
+    if (active == 0) {
+        // no band contributes: result = 0 (/ out_div) * out_scale, evaluated on the device
+        d.nbands = 1;
+        d.band_scale[0] = 1.0f;
+        d.band_w[0] = 0.0f;
+    }
+    hipLaunchKernelGGL(grid3d_direct_kernel, dim3(grid_blocks(total)), dim3(256), 0,
+                       as_stream(stream), d);
+    WN_LAUNCH_CHECK("grid3d_direct_kernel(multiband)");
+    return WN_OK;
+}
+
+int wn_eval2d_grid(const wn_tile *tile, const wn_grid *grid, float *out_dev, void *stream)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    if (!tile) return fail(WN_ERR_INVALID, "tile is NULL");
+    if (tile->count && tile->dims != 2) return fail(WN_ERR_INVALID, "wn_eval2d_grid needs a 2-D tile");
+    GridArgs g;
+    rc = check_grid(grid, false, &g);
+    if (rc) return rc;
+    const size_t total = (size_t)g.nx * g.ny;
+    if (total == 0) return WN_OK;
+    if (!out_dev) return fail(WN_ERR_INVALID, "out_dev is NULL");
+    DirectArgs d{};
+    d.coef = tile->dev;
+    d.out = out_dev;
+    d.n = tile->n;
+    d.nmask = pow2_mask(tile->n);
+    d.g = g;
+    hipLaunchKernelGGL(grid2d_direct_kernel, dim3(grid_blocks(total)), dim3(256), 0,
+                       as_stream(stream), d);
+    WN_LAUNCH_CHECK("grid2d_direct_kernel");
+    return WN_OK;
+}
+
+int wn_eval3d_projected_grid(const wn_tile *tile, const wn_grid *grid, const float normal[3],
+                             float *out_dev, void *stream)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    if (!tile || !normal) return fail(WN_ERR_INVALID, "tile/normal is NULL");
+    if (tile->count && tile->dims != 3)
+        return fail(WN_ERR_INVALID, "wn_eval3d_projected_grid needs a 3-D tile");
+    GridArgs g;
+    rc = check_grid(grid, true, &g);
+    if (rc) return rc;
+    const size_t total = (size_t)g.nx * g.ny * g.nz;
+    if (total == 0) return WN_OK;
+    if (!out_dev) return fail(WN_ERR_INVALID, "out_dev is NULL");
+    ProjGridArgs a{};
+    a.coef = tile->dev;
+    a.out = out_dev;
+    a.n = tile->n;
+    a.nmask = pow2_mask(tile->n);
+    a.g = g;
+    for (int i = 0; i < 3; ++i) a.normal[i] = normal[i];
+    hipLaunchKernelGGL(grid3d_projected_kernel, dim3(grid_blocks(total)), dim3(256), 0,
+                       as_stream(stream), a);
+    WN_LAUNCH_CHECK("grid3d_projected_kernel");
+    return WN_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,331 @@
+// wn_wavelet_points.hip -- wavelet noise on arbitrary point lists (K2 / K3-points / K3p of
+// SURVEY.md 8) and the wavelet_texture adaptor over ray hit points.
+//
+// One point per lane; the 27 (or 9) coefficient gathers come straight from the tile in HBM
+// (8 MiB: L2 / Infinity-Cache resident), arithmetic in the reference's order and unfused, so
+// every result is bit-identical to the scalar CPU member it batches.  The texture kernel takes
+// an optional per-point `active` byte: each wave compacts its active hits with __ballot +
+// prefix popcount into a per-wave LDS queue and only runs the gather loop on full 64-lane
+// batches, so rays that missed the noise-textured surfaces cost no gather slots.
+#include "wn_internal.hpp"
+#include "wn_device_eval.hpp"
+
+#include <cmath>
+
+namespace {
+
+constexpr int kMaxBands = 8;
+
+struct PointsArgs {
+    const float *coef;
+    int n, nmask;
+    const float *pts;     // xyz (or xy) interleaved
+    const float *normals; // projected only
+    float *out;
+    size_t count;
+    // multiband
+    int nbands;
+    float band_scale[kMaxBands], band_w[kMaxBands];
+    float out_div;
+    int apply_div;
+};
+
+__global__ __launch_bounds__(256) void eval3d_points_kernel(const PointsArgs a)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.count;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float *p = a.pts + 3 * i;
+        a.out[i] = wn::eval3d_exact(a.coef, a.n, a.nmask, p[0], p[1], p[2]);
+    }
+}
+
+__global__ __launch_bounds__(256) void eval2d_points_kernel(const PointsArgs a)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.count;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float *p = a.pts + 2 * i;
+        a.out[i] = wn::eval2d_exact(a.coef, a.n, a.nmask, p[0], p[1]);
+    }
+}
+
+__global__ __launch_bounds__(256) void eval3d_projected_points_kernel(const PointsArgs a)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.count;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float p[3] = {a.pts[3 * i], a.pts[3 * i + 1], a.pts[3 * i + 2]};
+        const float nr[3] = {a.normals[3 * i], a.normals[3 * i + 1], a.normals[3 * i + 2]};
+        a.out[i] = wn::projected_exact(a.coef, a.n, a.nmask, p, nr);
+    }
+}
+
+// WMultibandNoise (paper Appendix 2, normal == NULL) per point.
+__global__ __launch_bounds__(256) void multiband3d_points_kernel(const PointsArgs a)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.count;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float *p = a.pts + 3 * i;
+        float v = 0.0f;
+        for (int b = 0; b < a.nbands; ++b) {
+            const float s = a.band_scale[b];
+            v += a.band_w[b] * wn::eval3d_exact(a.coef, a.n, a.nmask, 2.0f * p[0] * s,
+                                                2.0f * p[1] * s, 2.0f * p[2] * s);
+        }
+        if (a.apply_div) v /= a.out_div;
+        a.out[i] = v;
+    }
+}
+
+// ---- wavelet_texture::value (texture.h:67-107) --------------------------------------------------
+struct TexArgs {
+    const float *coef;
+    int n, nmask;
+    int mode; // 3: evaluate3D branch, 2: evaluate2D branch, 0: no tile (texture.h:100-102)
+    double scale;
+    float octave_mul; // octave_scale * 2.0f   (texture.h:77-80)
+    float inv_stddev; // 1/sqrt(0.18402f) or 1/sqrt(0.19686f)
+    const float *pts;
+    const uint8_t *active;
+    float *grey;
+    size_t count;
+    int points_per_wave;
+};
+
+__device__ __forceinline__ float wavelet_texture_value(const TexArgs &a, float px, float py,
+                                                       float pz)
+{
+    double v;
+    if (a.mode == 3) {
+        float pos[3] = {(float)((double)px * a.scale), (float)((double)py * a.scale),
+                        (float)((double)pz * a.scale)};
+        pos[0] *= a.octave_mul;
+        pos[1] *= a.octave_mul;
+        pos[2] *= a.octave_mul;
+        v = (double)wn::eval3d_exact(a.coef, a.n, a.nmask, pos[0], pos[1], pos[2]);
+        v *= (double)a.inv_stddev;
+    } else if (a.mode == 2) {
+        float pos[2] = {(float)((double)px * a.scale), (float)((double)py * a.scale)};
+        pos[0] *= a.octave_mul;
+        pos[1] *= a.octave_mul;
+        v = (double)wn::eval2d_exact(a.coef, a.n, a.nmask, pos[0], pos[1]);
+        v *= (double)a.inv_stddev;
+    } else {
+        v = 0.0;
+    }
+    const double q = v / 4.0;
+    const double c = (q < -1.0) ? -1.0 : ((1.0 < q) ? 1.0 : q); // std::clamp
+    return (float)(0.5 * (1.0 + c));                              // texture.h:104-106
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(256) void wavelet_texture_kernel(const TexArgs a)
+{
+    // per-wave compaction queue: up to 63 carried + 64 new hits
+    __shared__ float q_x[4][128], q_y[4][128], q_z[4][128];
+    __shared__ unsigned q_i[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t gwave = (size_t)blockIdx.x * 4 + wave;
+    const size_t begin = gwave * (size_t)a.points_per_wave;
+    if (begin >= a.count) return;
+    const size_t end = min(a.count, begin + (size_t)a.points_per_wave);
+
+    if (!MASKED) {
+        for (size_t i = begin + lane; i < end; i += 64) {
+            const float *p = a.pts + 3 * i;
+            a.grey[i] = wavelet_texture_value(a, p[0], p[1], p[2]);
+        }
+        return;
+    }
+
+    int queued = 0; // wave-uniform
+    for (size_t base = begin; base < end; base += 64) {
+        const size_t i = base + lane;
+        const bool hit = (i < end) && (a.active[i] != 0);
+        const unsigned long long ballot = __ballot(hit);
+        if (hit) {
+            const int slot = queued + __popcll(ballot & ((1ull << lane) - 1ull));
+            const float *p = a.pts + 3 * i;
+            q_x[wave][slot] = p[0];
+            q_y[wave][slot] = p[1];
+            q_z[wave][slot] = p[2];
+            q_i[wave][slot] = (unsigned)(i - begin);
+        }
+        queued += __popcll(ballot);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (queued >= 64) { // a full batch: every lane gathers
+            const float x = q_x[wave][lane], y = q_y[wave][lane], z = q_z[wave][lane];
+            const unsigned idx = q_i[wave][lane];
+            // carry the remainder down before the (long) evaluation
+            const int rest = queued - 64;
+            float cx = 0, cy = 0, cz = 0;
+            unsigned ci = 0;
+            if (lane < rest) {
+                cx = q_x[wave][64 + lane];
+                cy = q_y[wave][64 + lane];
+                cz = q_z[wave][64 + lane];
+                ci = q_i[wave][64 + lane];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane < rest) {
+                q_x[wave][lane] = cx;
+                q_y[wave][lane] = cy;
+                q_z[wave][lane] = cz;
+                q_i[wave][lane] = ci;
+            }
+            queued = rest;
+            a.grey[begin + idx] = wavelet_texture_value(a, x, y, z);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+    if (lane < queued) { // tail batch
+        const unsigned idx = q_i[wave][lane];
+        a.grey[begin + idx] =
+            wavelet_texture_value(a, q_x[wave][lane], q_y[wave][lane], q_z[wave][lane]);
+    }
+}
+
+inline int pow2_mask(int n) { return (n > 0 && (n & (n - 1)) == 0) ? n - 1 : -1; }
+inline int point_blocks(size_t total)
+{
+    size_t b = (total + 255) / 256;
+    const size_t cap = 256u * 8u * 8u;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+int fill_common(const wn_tile *tile, int dims, const void *pts, size_t n, const void *out,
+                PointsArgs *a)
+{
+    if (!tile) return wn::fail(WN_ERR_INVALID, "tile is NULL");
+    if (tile->count && tile->dims != dims)
+        return wn::fail(WN_ERR_INVALID, "tile is %d-D, this entry point needs %d-D", tile->dims, dims);
+    if (n && (!pts || !out)) return wn::fail(WN_ERR_INVALID, "points/out pointer is NULL");
+    a->coef = tile->dev;
+    a->n = tile->n;
+    a->nmask = pow2_mask(tile->n);
+    a->count = n;
+    return WN_OK;
+}
+
+} // namespace
+
+using namespace wn;
+
+extern "C" {
+
+int wn_eval3d_points(const wn_tile *tile, const float *xyz_dev, size_t n, float *out_dev,
+                     void *stream)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    PointsArgs a{};
+    rc = fill_common(tile, 3, xyz_dev, n, out_dev, &a);
+    if (rc || n == 0) return rc;
+    a.pts = xyz_dev;
+    a.out = out_dev;
+    hipLaunchKernelGGL(eval3d_points_kernel, dim3(point_blocks(n)), dim3(256), 0, as_stream(stream), a);
+    WN_LAUNCH_CHECK("eval3d_points_kernel");
+    return WN_OK;
+}
+
+int wn_eval2d_points(const wn_tile *tile, const float *xy_dev, size_t n, float *out_dev,
+                     void *stream)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    PointsArgs a{};
+    rc = fill_common(tile, 2, xy_dev, n, out_dev, &a);
+    if (rc || n == 0) return rc;
+    a.pts = xy_dev;
+    a.out = out_dev;
+    hipLaunchKernelGGL(eval2d_points_kernel, dim3(point_blocks(n)), dim3(256), 0, as_stream(stream), a);
+    WN_LAUNCH_CHECK("eval2d_points_kernel");
+    return WN_OK;
+}
+
+int wn_eval3d_projected_points(const wn_tile *tile, const float *xyz_dev, const float *normals_dev,
+                               size_t n, float *out_dev, void *stream)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    PointsArgs a{};
+    rc = fill_common(tile, 3, xyz_dev, n, out_dev, &a);
+    if (rc || n == 0) return rc;
+    if (!normals_dev) return fail(WN_ERR_INVALID, "normals_dev is NULL");
+    a.pts = xyz_dev;
+    a.normals = normals_dev;
+    a.out = out_dev;
+    hipLaunchKernelGGL(eval3d_projected_points_kernel, dim3(point_blocks(n)), dim3(256), 0,
+                       as_stream(stream), a);
+    WN_LAUNCH_CHECK("eval3d_projected_points_kernel");
+    return WN_OK;
+}
+
+int wn_multiband3d_points(const wn_tile *tile, const float *xyz_dev, size_t n, float s,
+                          int first_band, int nbands, const float *w_host, float var_per_band,
+                          float *out_dev, void *stream)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    if (nbands < 0 || nbands > kMaxBands)
+        return fail(WN_ERR_INVALID, "nbands must be in 0..%d (got %d)", kMaxBands, nbands);
+    if (nbands && !w_host) return fail(WN_ERR_INVALID, "w_host is NULL");
+    PointsArgs a{};
+    rc = fill_common(tile, 3, xyz_dev, n, out_dev, &a);
+    if (rc || n == 0) return rc;
+    a.pts = xyz_dev;
+    a.out = out_dev;
+    int active = 0;
+    while (active < nbands && s + (float)first_band + (float)active < 0.0f) ++active;
+    float variance = 0.0f;
+    for (int b = 0; b < nbands; ++b) variance += w_host[b] * w_host[b];
+    a.nbands = active;
+    for (int b = 0; b < active; ++b) {
+        a.band_scale[b] = ldexpf(1.0f, first_band + b);
+        a.band_w[b] = w_host[b];
+    }
+    a.apply_div = variance != 0.0f;
+    a.out_div = a.apply_div ? sqrtf(variance * var_per_band) : 1.0f;
+    hipLaunchKernelGGL(multiband3d_points_kernel, dim3(point_blocks(n)), dim3(256), 0,
+                       as_stream(stream), a);
+    WN_LAUNCH_CHECK("multiband3d_points_kernel");
+    return WN_OK;
+}
+
+int wn_wavelet_texture_points(const wn_tile *tile, int use_3d, double scale, int octave,
+                              const float *xyz_dev, const uint8_t *active_dev, size_t n,
+                              float *grey_dev, void *stream)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    if (n == 0) return WN_OK;
+    if (!xyz_dev || !grey_dev) return fail(WN_ERR_INVALID, "points/grey pointer is NULL");
+    TexArgs a{};
+    const bool has_tile = tile && tile->count != 0;
+    if (has_tile && tile->dims != (use_3d ? 3 : 2))
+        return fail(WN_ERR_INVALID, "tile is %d-D but use_3d=%d", tile->dims, use_3d);
+    a.coef = has_tile ? tile->dev : nullptr;
+    a.n = has_tile ? tile->n : 0;
+    a.nmask = pow2_mask(a.n);
+    a.mode = has_tile ? (use_3d ? 3 : 2) : 0;
+    a.scale = scale;
+    const float octave_scale = (float)std::pow(2.0, (double)octave); // texture.h:77
+    a.octave_mul = octave_scale * 2.0f;
+    a.inv_stddev = 1.0f / std::sqrt(use_3d ? 0.18402f : 0.19686f);   // texture.h:84,98
+    a.pts = xyz_dev;
+    a.active = active_dev;
+    a.grey = grey_dev;
+    a.count = n;
+    a.points_per_wave = 1024;
+    const size_t waves = (n + a.points_per_wave - 1) / a.points_per_wave;
+    const size_t blocks = (waves + 3) / 4;
+    if (blocks > 0x7fffffffull) return fail(WN_ERR_INVALID, "too many points");
+    if (active_dev)
+        hipLaunchKernelGGL(wavelet_texture_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
+                           as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(wavelet_texture_kernel<false>, dim3((unsigned)blocks), dim3(256), 0,
+                           as_stream(stream), a);
+    WN_LAUNCH_CHECK("wavelet_texture_kernel");
+    return WN_OK;
+}
+
+} // extern "C"
