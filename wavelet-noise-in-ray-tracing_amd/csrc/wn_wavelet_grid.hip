@@ -50,6 +50,7 @@ struct SepArgs {
     int nbx, nby, nbz;
     int nbands;
     float out_div;
+    float inv_den; // 1/den when den is a power of two (exact), else 0
     int vec4_ok;
     BandArgs band[kMaxBands];
 };
@@ -63,6 +64,17 @@ __device__ __forceinline__ int xcd_remap(int id, int total)
     const int xcd = id & 7, k = id >> 3;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + k;
+}
+
+// lattice_coord with the division replaced by an exact multiply when den is a power of two.
+__device__ __forceinline__ float lattice_coord_fast(int i, float den, float inv_den, float range,
+                                                    float oscale, float post)
+{
+    const float fi = (float)i;
+    float c = ((inv_den != 0.0f) ? fi * inv_den : fi / den) * range;
+    c = c * oscale;
+    c = c * post;
+    return c;
 }
 
 template <int NB>
@@ -96,8 +108,8 @@ __global__ __launch_bounds__(256) void grid3d_sep_kernel(const SepArgs a)
                 is_const = g.z_const_mode != 0;
             } else idx = (slot == 24) ? x_first : x_last;
             float c = is_const ? g.z_const
-                               : wn::lattice_coord(idx, den, g.base_range, a.band[b].oscale,
-                                                   g.post_scale);
+                               : lattice_coord_fast(idx, den, a.inv_den, g.base_range,
+                                                    a.band[b].oscale, g.post_scale);
             int m;
             float w0, w1, w2;
             wn::bspline(c, m, w0, w1, w2);
@@ -112,8 +124,10 @@ __global__ __launch_bounds__(256) void grid3d_sep_kernel(const SepArgs a)
     const int x0 = x_first + lane * 4;
     float xbase[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        xbase[q] = ((float)min(x0 + q, g.nx - 1) / den) * g.base_range;
+    for (int q = 0; q < 4; ++q) {
+        const float xi = (float)min(x0 + q, g.nx - 1);
+        xbase[q] = ((a.inv_den != 0.0f) ? xi * a.inv_den : xi / den) * g.base_range;
+    }
     float ww[NB][4][4];
     int wmid0[NB];
 #pragma unroll
@@ -129,22 +143,22 @@ __global__ __launch_bounds__(256) void grid3d_sep_kernel(const SepArgs a)
         wmid0[b] = m[0];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int d = m[q] - m[0]; // 0 or 1 (host guarantees step <= 1/3)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int tap = c - d;
-                ww[b][q][c] = (tap == 0) ? w[q][0] : (tap == 1) ? w[q][1] : (tap == 2) ? w[q][2] : 0.0f;
-            }
+            const bool up = m[q] != m[0]; // mid is m[0] or m[0]+1 (host guarantees step <= 1/3)
+            ww[b][q][0] = up ? 0.0f : w[q][0];
+            ww[b][q][1] = up ? w[q][0] : w[q][1];
+            ww[b][q][2] = up ? w[q][1] : w[q][2];
+            ww[b][q][3] = up ? w[q][2] : 0.0f;
         }
     }
     __syncthreads();
 
     // ---- stage 0: coefficient boxes -> LDS (periodic wrap resolved here) -----------------------
-    int ix0[NB], jy0[NB], kz0[NB], EX[NB], EY[NB], EZ[NB];
+    int ix0[NB], jy0[NB], kz0[NB], EX[NB], EY[NB], EZ[NB], RS[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         ix0[b] = s_mid[b][24] - 1;
         EX[b] = s_mid[b][25] - s_mid[b][24] + 4; // +3 support, +1 pad column (zero-weight tap)
+        RS[b] = EX[b] | 1;                       // odd row stride of R: conflict-free column writes
         jy0[b] = s_mid[b][0] - 1;
         EY[b] = s_mid[b][BY - 1] - s_mid[b][0] + 3;
         kz0[b] = s_mid[b][16] - 1;
@@ -161,32 +175,33 @@ __global__ __launch_bounds__(256) void grid3d_sep_kernel(const SepArgs a)
     }
     __syncthreads();
 
-    // ---- phase 1: collapse y and z: R[row][i] = sum_k wz[k] sum_j wy[j] C[k][j][i] --------------
+    // ---- phase 1: collapse y and z.  Lane = sample row (its 9 yz-weights live in registers),
+    //      the 4 waves split the coefficient columns:
+    //      R[row][i] = out_scale * sum_k sum_j (wz[k]*wy[j]) * C[kz+k][jy+j][i]
+    if (lane < rows) {
+        const int yi = lane & (BY - 1), zi = lane >> a.by_log2;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const float *box = lds + a.band[b].box_off;
-        float *R = lds + a.band[b].r_off;
-        const int ex = EX[b], ey = EY[b];
-        const int total = rows * ex;
-        const float inv_ex = 1.0f / (float)ex;
-        for (int e = tid; e < total; e += 256) {
-            const int row = (int)(((float)e + 0.5f) * inv_ex);
-            const int i = e - row * ex;
-            const int yi = row & (BY - 1), zi = row >> a.by_log2;
-            const int jy = s_mid[b][yi] - 1 - jy0[b];
-            const int kz = s_mid[b][16 + zi] - 1 - kz0[b];
-            const float wy0 = s_w[b][yi][0], wy1 = s_w[b][yi][1], wy2 = s_w[b][yi][2];
-            const float *c = box + (kz * ey + jy) * ex + i;
-            float acc = 0.0f;
+        for (int b = 0; b < NB; ++b) {
+            const int ex = EX[b], ey = EY[b];
+            const float *c = lds + a.band[b].box_off +
+                             ((s_mid[b][16 + zi] - 1 - kz0[b]) * ey + (s_mid[b][yi] - 1 - jy0[b])) * ex;
+            float *R = lds + a.band[b].r_off + lane * RS[b];
+            float w9[3][3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float *ck = c + k * ey * ex;
-                float t = wy0 * ck[0];
-                t = __builtin_fmaf(wy1, ck[ex], t);
-                t = __builtin_fmaf(wy2, ck[2 * ex], t);
-                acc = __builtin_fmaf(s_w[b][16 + zi][k], t, acc);
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) w9[k][j] = s_w[b][16 + zi][k] * s_w[b][yi][j];
+            const int chunk = (ex + 3) >> 2;
+            const int i_end = min(ex, (wave + 1) * chunk);
+            for (int i = wave * chunk; i < i_end; ++i) {
+                float acc = w9[0][0] * c[i];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (k | j) acc = __builtin_fmaf(w9[k][j], c[(k * ey + j) * ex + i], acc);
+                R[i] = (NB == 1) ? acc * g.out_scale : acc;
             }
-            R[e] = acc;
         }
     }
     __syncthreads();
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(256) void grid3d_sep_kernel(const SepArgs a)
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const float *R = lds + a.band[b].r_off + row * EX[b] + (wmid0[b] - 1 - ix0[b]);
+            const float *R = lds + a.band[b].r_off + row * RS[b] + (wmid0[b] - 1 - ix0[b]);
             const float v0 = R[0], v1 = R[1], v2 = R[2], v3 = R[3];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -212,10 +227,9 @@ __global__ __launch_bounds__(256) void grid3d_sep_kernel(const SepArgs a)
                 else acc[q] = __builtin_fmaf(a.band[b].weight, t, acc[q]);
             }
         }
+        if (NB > 1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (NB > 1) acc[q] = acc[q] / a.out_div;
-            acc[q] = acc[q] * g.out_scale;
+            for (int q = 0; q < 4; ++q) acc[q] = (acc[q] / a.out_div) * g.out_scale;
         }
         if (!lane_in) continue;
         float *dst = a.out + ((size_t)z * g.ny + y) * g.nx + x0;
@@ -371,7 +385,7 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
         a->band[b].box_off = (int)off;
         off += (size_t)ex * ey * ez;
         a->band[b].r_off = (int)off;
-        off += (size_t)rows * ex + 4;
+        off += (size_t)rows * (ex | 1) + 4;
     }
     *lds_bytes = off * sizeof(float);
     if (*lds_bytes > 60 * 1024) return false;
@@ -387,6 +401,7 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
     a->n = tile->n;
     a->nmask = pow2_mask(tile->n);
     a->g = g;
+    a->inv_den = ((g.den & (g.den - 1)) == 0) ? 1.0f / (float)g.den : 0.0f;
     return true;
 }
 

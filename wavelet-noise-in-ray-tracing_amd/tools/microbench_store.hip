@@ -1,0 +1,80 @@
+// microbench_store.hip -- development tool: what can one MI355X sustain for a pure fp32 store
+// stream of the dense-grid shape?  (The 512^3 grid kernel is bound by its 512 MiB store.)
+// Build: hipcc --offload-arch=gfx950 -O3 microbench_store.hip -o microbench_store
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <bool NT>
+__global__ __launch_bounds__(256) void fill_linear(float4 *out, size_t n4, float v)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 x = make_float4(v, v + 1, v + 2, v + 3);
+        if (NT) __builtin_nontemporal_store(v4f{x.x, x.y, x.z, x.w}, reinterpret_cast<v4f *>(out + i)); else out[i] = x;
+    }
+}
+
+// brick pattern of grid3d_sep_kernel: WG = 256 x 8 x 8 samples of a 512^3 volume; wave w writes
+// rows w, w+4, ... (1 KiB per wave store).
+template <bool NT>
+__global__ __launch_bounds__(256) void fill_bricks(float *out, int N, float v)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int b = blockIdx.x;
+    const int nbx = N / 256, nby = N / 8;
+    const int bx = b % nbx; b /= nbx;
+    const int by = b % nby, bz = b / nby;
+    for (int row = wave; row < 64; row += 4) {
+        const int y = by * 8 + (row & 7), z = bz * 8 + (row >> 3);
+        float4 x = make_float4(v, v + row, v + 2, v + 3);
+        float4 *dst = reinterpret_cast<float4 *>(out + ((size_t)z * N + y) * N + bx * 256 + lane * 4);
+        if (NT) __builtin_nontemporal_store(v4f{x.x, x.y, x.z, x.w}, reinterpret_cast<v4f *>(dst)); else *dst = x;
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_linear(const float4 *in, float4 *out, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = in[i];
+}
+
+template <typename F>
+float time_it(F launch, int iters)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 3; ++i) launch();
+    std::vector<float> ms;
+    for (int r = 0; r < 5; ++r) {
+        hipEventRecord(a);
+        for (int i = 0; i < iters; ++i) launch();
+        hipEventRecord(b); hipEventSynchronize(b);
+        float t; hipEventElapsedTime(&t, a, b); ms.push_back(t / iters);
+    }
+    std::sort(ms.begin(), ms.end());
+    return ms[2];
+}
+
+int main()
+{
+    const int N = 512;
+    const size_t n = (size_t)N * N * N, bytes = n * 4;
+    float *out, *in;
+    CK(hipMalloc(&out, bytes)); CK(hipMalloc(&in, bytes)); CK(hipMemset(in, 0, bytes));
+    auto report = [&](const char *name, float ms, double b) { printf("%-34s %8.1f us  %7.1f GB/s\n", name, ms * 1e3, b / ms / 1e6); };
+    for (int blocks : {2048, 8192, 32768}) {
+        char nm[64];
+        snprintf(nm, 64, "fill_linear plain  grid=%d", blocks);
+        report(nm, time_it([&] { fill_linear<false><<<blocks, 256>>>((float4 *)out, n / 4, 1.f); }, 20), bytes);
+        snprintf(nm, 64, "fill_linear nt     grid=%d", blocks);
+        report(nm, time_it([&] { fill_linear<true><<<blocks, 256>>>((float4 *)out, n / 4, 1.f); }, 20), bytes);
+    }
+    report("fill_bricks plain", time_it([&] { fill_bricks<false><<<(N / 256) * (N / 8) * (N / 8), 256>>>(out, N, 1.f); }, 20), bytes);
+    report("fill_bricks nt", time_it([&] { fill_bricks<true><<<(N / 256) * (N / 8) * (N / 8), 256>>>(out, N, 1.f); }, 20), bytes);
+    report("copy_linear (read+write bytes)", time_it([&] { copy_linear<<<8192, 256>>>((const float4 *)in, (float4 *)out, n / 4); }, 20), 2.0 * bytes);
+    hipMemsetAsync(out, 0, bytes);
+    report("hipMemsetAsync", time_it([&] { hipMemsetAsync(out, 0, bytes); }, 20), bytes);
+    return 0;
+}
