@@ -23,16 +23,24 @@
 #include "wn_internal.hpp"
 #include "wn_device_eval.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
 using wn::GridArgs;
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 constexpr int kMaxBands = 8;
-constexpr int kBrickX = 256;     // samples per brick along x (64 lanes x 4)
-constexpr int kMaxRows = 64;     // BY*BZ
-constexpr int kMaxBY = 16, kMaxBZ = 8;
+constexpr int kBrickX = 256;  // samples per brick along x (64 lanes x 4)
+constexpr int kBrickY = 8;    // sample rows per brick along y
+constexpr int kMaxBZ = 8;     // ... and along z (power of two <= 8, fewer for thin slabs)
+constexpr int kBoxY = 6;      // coefficient box: at most 6 rows in y and in z (8 samples, step <= 1/3)
+constexpr int kBoxZ = 6;
+constexpr int kColStride = kBoxY * kBoxZ + 1; // LDS floats per box column (odd: conflict-free fills)
+constexpr int kPrefetch = 8;  // coefficient-box values a lane keeps in flight per band
 
 struct BandArgs {
     float oscale; // octave_scale of this band
@@ -46,7 +54,8 @@ struct SepArgs {
     float *out;
     int n, nmask;
     GridArgs g;
-    int by_log2, bz_log2;
+    int bz_log2;
+    int box_buf_stride; // floats between the two copies of the box region (double buffering)
     int nbx, nby, nbz;
     int nbands;
     float out_div;
@@ -56,8 +65,8 @@ struct SepArgs {
 };
 
 // Bijective XCD-aware remap: hardware deals consecutive workgroup ids round-robin over the 8
-// XCDs, so ids congruent mod 8 share an L2.  Give each XCD one contiguous range of bricks
-// (contiguous z-range of the volume => 1/8 of the tile per L2).
+// XCDs, so ids congruent mod 8 share an L2.  Give each XCD one contiguous range of workgroups
+// (hence of bricks => a contiguous part of the volume and of the tile per L2).  Speed only.
 __device__ __forceinline__ int xcd_remap(int id, int total)
 {
     const int q = total >> 3, r = total & 7;
@@ -77,168 +86,297 @@ __device__ __forceinline__ float lattice_coord_fast(int i, float den, float inv_
     return c;
 }
 
+// Persistent workgroups: each of the gridDim.x workgroups owns a contiguous range of bricks
+// (brick id = bx * (nby*nbz) + by + nby*bz, so a range mostly keeps bx, and with it the lane's
+// x-window weights, fixed) and runs a two-barrier pipeline per brick:
+//     [write prefetched coefficient box to LDS | tables of the next brick]   barrier
+//     [phase 1: collapse y,z -> R rows]                                      barrier
+//     [issue the next brick's coefficient loads | phase C: x-window -> float4 stores]
+// LDS images per band:
+//     box[i][k][j]  column-major coefficient box, i = x column, fixed strides (kColStride, kBoxY)
+//                   so that a row's 9 (k,j) taps are immediate offsets from one address;
+//     R[row][i]     collapsed rows, odd row stride.
 template <int NB>
 __global__ __launch_bounds__(256) void grid3d_sep_kernel(const SepArgs a)
 {
     extern __shared__ float lds[];
-    // per-band sample tables: slots 0..15 y samples, 16..23 z samples, 24/25 first/last x
-    __shared__ int s_mid[NB][32];
-    __shared__ float s_w[NB][32][3];
+    // per-band sample tables, double buffered: slots 0..7 y samples, 8..15 z samples,
+    // 16/17 first/last x sample of the brick
+    __shared__ int s_mid[2][NB][32];
+    __shared__ float s_w[2][NB][16][3];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int BY = 1 << a.by_log2, BZ = 1 << a.bz_log2, rows = BY * BZ;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int BZ = 1 << a.bz_log2, rows = kBrickY * BZ;
     const GridArgs &g = a.g;
     const float den = (float)g.den;
+    const int nyz = a.nby * a.nbz;
 
-    int brick = xcd_remap(blockIdx.x, a.nbx * a.nby * a.nbz);
-    const int bx = brick % a.nbx;
-    brick /= a.nbx;
-    const int by = brick % a.nby, bz = brick / a.nby;
-    const int x_first = bx * kBrickX, x_last = min(x_first + kBrickX - 1, g.nx - 1);
+    const long long total_items = (long long)a.nbx * nyz;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    int item = (int)(total_items * wg / gridDim.x);
+    const int item_end = (int)(total_items * (wg + 1) / gridDim.x);
+    if (item >= item_end) return;
+    int bx = item / nyz;
+    int bz = (item - bx * nyz) / a.nby;
+    int by = item - bx * nyz - bz * a.nby;
 
-    // ---- per-band tables --------------------------------------------------------------------
-    {
+    auto fill_tables = [&](int buf, int tbx, int tby, int tbz) {
         const int b = tid >> 5, slot = tid & 31;
-        if (b < NB) {
-            int idx = 0;
+        if (b < NB && slot < 18) {
+            int idx;
             bool is_const = false;
-            if (slot < 16) idx = min(by * BY + min(slot, BY - 1), g.ny - 1);
-            else if (slot < 24) {
-                idx = g.z0 + min(bz * BZ + min(slot - 16, BZ - 1), g.nz - 1);
+            if (slot < 8) idx = min(tby * kBrickY + slot, g.ny - 1);
+            else if (slot < 16) {
+                idx = g.z0 + min(tbz * BZ + min(slot - 8, BZ - 1), g.nz - 1);
                 is_const = g.z_const_mode != 0;
-            } else idx = (slot == 24) ? x_first : x_last;
-            float c = is_const ? g.z_const
-                               : lattice_coord_fast(idx, den, a.inv_den, g.base_range,
-                                                    a.band[b].oscale, g.post_scale);
+            } else idx = (slot == 16) ? tbx * kBrickX : min(tbx * kBrickX + kBrickX - 1, g.nx - 1);
+            const float c = is_const ? g.z_const
+                                     : lattice_coord_fast(idx, den, a.inv_den, g.base_range,
+                                                          a.band[b].oscale, g.post_scale);
             int m;
             float w0, w1, w2;
             wn::bspline(c, m, w0, w1, w2);
-            s_mid[b][slot] = m;
-            s_w[b][slot][0] = w0;
-            s_w[b][slot][1] = w1;
-            s_w[b][slot][2] = w2;
+            s_mid[buf][b][slot] = m;
+            if (slot < 16) {
+                s_w[buf][b][slot][0] = w0;
+                s_w[buf][b][slot][1] = w1;
+                s_w[buf][b][slot][2] = w2;
+            }
         }
-    }
+    };
 
-    // ---- this lane's 4 x samples: window base and 16 window weights per band -------------------
-    const int x0 = x_first + lane * 4;
-    float xbase[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float xi = (float)min(x0 + q, g.nx - 1);
-        xbase[q] = ((a.inv_den != 0.0f) ? xi * a.inv_den : xi / den) * g.base_range;
-    }
-    float ww[NB][4][4];
-    int wmid0[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        int m[4];
-        float w[4][3];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float c = xbase[q] * a.band[b].oscale;
-            c = c * g.post_scale;
-            wn::bspline(c, m[q], w[q][0], w[q][1], w[q][2]);
-        }
-        wmid0[b] = m[0];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool up = m[q] != m[0]; // mid is m[0] or m[0]+1 (host guarantees step <= 1/3)
-            ww[b][q][0] = up ? 0.0f : w[q][0];
-            ww[b][q][1] = up ? w[q][0] : w[q][1];
-            ww[b][q][2] = up ? w[q][1] : w[q][2];
-            ww[b][q][3] = up ? w[q][2] : 0.0f;
-        }
-    }
-    __syncthreads();
+    // coefficient-box geometry of a brick, read back from its tables (wave-uniform)
+    struct Box { int ix0, jy0, kz0, ex, ey, ez; };
+    auto box_of = [&](int buf, int b) {
+        Box o;
+        o.ix0 = s_mid[buf][b][16] - 1;
+        o.ex = s_mid[buf][b][17] - s_mid[buf][b][16] + 4; // +3 support, +1 pad column (zero-weight tap)
+        o.jy0 = s_mid[buf][b][0] - 1;
+        o.ey = s_mid[buf][b][kBrickY - 1] - s_mid[buf][b][0] + 3;
+        o.kz0 = s_mid[buf][b][8] - 1;
+        o.ez = s_mid[buf][b][8 + BZ - 1] - s_mid[buf][b][8] + 3;
+        return o;
+    };
 
-    // ---- stage 0: coefficient boxes -> LDS (periodic wrap resolved here) -----------------------
-    int ix0[NB], jy0[NB], kz0[NB], EX[NB], EY[NB], EZ[NB], RS[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        ix0[b] = s_mid[b][24] - 1;
-        EX[b] = s_mid[b][25] - s_mid[b][24] + 4; // +3 support, +1 pad column (zero-weight tap)
-        RS[b] = EX[b] | 1;                       // odd row stride of R: conflict-free column writes
-        jy0[b] = s_mid[b][0] - 1;
-        EY[b] = s_mid[b][BY - 1] - s_mid[b][0] + 3;
-        kz0[b] = s_mid[b][16] - 1;
-        EZ[b] = s_mid[b][16 + BZ - 1] - s_mid[b][16] + 3;
-        float *box = lds + a.band[b].box_off;
-        const int nrows = EZ[b] * EY[b];
-        for (int r = wave; r < nrows; r += 4) {
-            const int k = r / EY[b], j = r - k * EY[b];
-            const float *src = a.coef + ((size_t)wn::dmod(kz0[b] + k, a.n, a.nmask) * a.n +
-                                         wn::dmod(jy0[b] + j, a.n, a.nmask)) * a.n;
-            for (int i = lane; i < EX[b]; i += 64)
-                box[r * EX[b] + i] = src[wn::dmod(ix0[b] + i, a.n, a.nmask)];
-        }
-    }
-    __syncthreads();
-
-    // ---- phase 1: collapse y and z.  Lane = sample row (its 9 yz-weights live in registers),
-    //      the 4 waves split the coefficient columns:
-    //      R[row][i] = out_scale * sum_k sum_j (wz[k]*wy[j]) * C[kz+k][jy+j][i]
-    if (lane < rows) {
-        const int yi = lane & (BY - 1), zi = lane >> a.by_log2;
+    // this lane's share of a band's box: element e = tid + 256*u, e = (k*ey + j)*ex + i (i fastest:
+    // coalesced global reads, conflict-free LDS fills thanks to the odd column stride)
+    float pf[NB][kPrefetch];
+    auto box_element = [&](const Box &o, int e, float inv_ex, float inv_ey, int &lds_idx) {
+        const int r = (int)(((float)e + 0.5f) * inv_ex), i = e - r * o.ex;
+        const int k = (int)(((float)r + 0.5f) * inv_ey), j = r - k * o.ey;
+        lds_idx = i * kColStride + k * kBoxY + j;
+        return (((o.kz0 + k) & a.nmask) * a.n + ((o.jy0 + j) & a.nmask)) * a.n + ((o.ix0 + i) & a.nmask);
+    };
+    auto issue_box = [&](int buf) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int ex = EX[b], ey = EY[b];
-            const float *c = lds + a.band[b].box_off +
-                             ((s_mid[b][16 + zi] - 1 - kz0[b]) * ey + (s_mid[b][yi] - 1 - jy0[b])) * ex;
-            float *R = lds + a.band[b].r_off + lane * RS[b];
-            float w9[3][3];
+            const Box o = box_of(buf, b);
+            const int count = o.ez * o.ey * o.ex;
+            const float inv_ex = 1.0f / (float)o.ex, inv_ey = 1.0f / (float)o.ey;
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+            for (int u = 0; u < kPrefetch; ++u) {
+                const int e = tid + 256 * u;
+                int unused;
+                pf[b][u] = (e < count) ? a.coef[box_element(o, e, inv_ex, inv_ey, unused)] : 0.0f;
+            }
+        }
+    };
+    auto commit_box = [&](int buf, int box_buf) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) w9[k][j] = s_w[b][16 + zi][k] * s_w[b][yi][j];
-            const int chunk = (ex + 3) >> 2;
-            const int i_end = min(ex, (wave + 1) * chunk);
-            for (int i = wave * chunk; i < i_end; ++i) {
-                float acc = w9[0][0] * c[i];
+        for (int b = 0; b < NB; ++b) {
+            const Box o = box_of(buf, b);
+            const int count = o.ez * o.ey * o.ex;
+            const float inv_ex = 1.0f / (float)o.ex, inv_ey = 1.0f / (float)o.ey;
+            float *box = lds + a.band[b].box_off + box_buf * a.box_buf_stride;
+#pragma unroll
+            for (int u = 0; u < kPrefetch; ++u) {
+                const int e = tid + 256 * u;
+                if (e < count) {
+                    int at;
+                    box_element(o, e, inv_ex, inv_ey, at);
+                    box[at] = pf[b][u];
+                }
+            }
+            // boxes larger than the prefetch window (steps near 1/3): the rest synchronously
+            for (int e = tid + 256 * kPrefetch; e < count; e += 256) {
+                int at;
+                const int src = box_element(o, e, inv_ex, inv_ey, at);
+                box[at] = a.coef[src];
+            }
+        }
+    };
+
+    // this lane's 4 x samples: window start (as a column of R) and 16 window weights per band;
+    // recomputed only when bx moves
+    float ww[NB][4][4];
+    int wbase[NB];
+    int x0 = 0;
+    auto x_weights = [&](int buf) {
+        x0 = bx * kBrickX + lane * 4;
+        float xbase[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xi = (float)min(x0 + q, g.nx - 1);
+            xbase[q] = ((a.inv_den != 0.0f) ? xi * a.inv_den : xi / den) * g.base_range;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            int m[4];
+            float w[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float c = xbase[q] * a.band[b].oscale;
+                c = c * g.post_scale;
+                wn::bspline(c, m[q], w[q][0], w[q][1], w[q][2]);
+            }
+            wbase[b] = m[0] - s_mid[buf][b][16]; // (m0 - 1) - ix0
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool up = m[q] != m[0]; // mid is m[0] or m[0]+1 (host guarantees step <= 1/3)
+                ww[b][q][0] = up ? 0.0f : w[q][0];
+                ww[b][q][1] = up ? w[q][0] : w[q][1];
+                ww[b][q][2] = up ? w[q][1] : w[q][2];
+                ww[b][q][3] = up ? w[q][2] : 0.0f;
+            }
+        }
+    };
+
+    // ---- pipeline ---------------------------------------------------------------------------------
+    // Tables and the coefficient box are double buffered (index = brick parity).  While brick t
+    // runs phase 1 out of box[t&1], the loads of box[(t+1)&1] are in flight; they are committed to
+    // LDS before barrier B2, i.e. BEFORE brick t's stores are issued, so the vmcnt wait that
+    // retires them only has the previous brick's (long finished) stores ahead of it.
+    auto next_brick = [&](int &nx_, int &ny_, int &nz_) {
+        if (++ny_ == a.nby) { ny_ = 0; ++nz_; }
+        if (nz_ == a.nbz) { nz_ = 0; ++nx_; }
+    };
+    int cur = 0;
+    fill_tables(0, bx, by, bz);
+    int n1x = bx, n1y = by, n1z = bz; // brick t+1
+    next_brick(n1x, n1y, n1z);
+    if (item + 1 < item_end) fill_tables(1, n1x, n1y, n1z);
+    __syncthreads();
+    issue_box(0);
+    commit_box(0, 0);
+    x_weights(0);
+    int weights_bx = bx;
+
+    for (;;) {
+        const bool has_next = item + 1 < item_end;
+        __syncthreads(); // B1: previous phase C done (R free); tables of brick t+1 visible; box[cur] complete
+
+        if (has_next) issue_box(cur ^ 1); // in flight during phase 1
+
+        // ---- phase 1: collapse y and z.  Lane = sample row (its 9 yz-weights in registers),
+        //      the 4 waves split the coefficient columns:
+        //      R[row][i] = out_scale * sum_k sum_j (wz[k]*wy[j]) * C[kz+k][jy+j][i]
+        int rs_[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) rs_[b] = (s_mid[cur][b][17] - s_mid[cur][b][16] + 4) | 1;
+        if (lane < rows) {
+            const int yi = lane & (kBrickY - 1), zi = lane >> 3;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int ex = s_mid[cur][b][17] - s_mid[cur][b][16] + 4;
+                const int kz = s_mid[cur][b][8 + zi] - s_mid[cur][b][8];  // row's first box row in z
+                const int jy = s_mid[cur][b][yi] - s_mid[cur][b][0];      // ... and in y
+                float w9[3][3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if (k | j) acc = __builtin_fmaf(w9[k][j], c[(k * ey + j) * ex + i], acc);
-                R[i] = (NB == 1) ? acc * g.out_scale : acc;
+                    for (int j = 0; j < 3; ++j) w9[k][j] = s_w[cur][b][8 + zi][k] * s_w[cur][b][yi][j];
+                const int chunk = (ex + 3) >> 2;
+                const int i_begin = wave * chunk, i_end = min(ex, i_begin + chunk);
+                const float *c = lds + a.band[b].box_off + cur * a.box_buf_stride + kz * kBoxY + jy +
+                                 i_begin * kColStride;
+                float *R = lds + a.band[b].r_off + lane * rs_[b] + i_begin;
+                for (int i = i_begin; i < i_end; ++i, c += kColStride, ++R) {
+                    float acc = w9[0][0] * c[0];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            if (k | j) acc = __builtin_fmaf(w9[k][j], c[k * kBoxY + j], acc);
+                    *R = (NB == 1) ? acc * g.out_scale : acc;
+                }
             }
         }
-    }
-    __syncthreads();
+        if (has_next) commit_box(cur ^ 1, cur ^ 1);
+        __syncthreads(); // B2: R rows and box[cur^1] complete; tables[cur] are dead
 
-    // ---- phase C: x from a 4-wide window of R, one float4 per lane per row ------------------------
-    const bool lane_in = x0 < g.nx;
-    for (int row = wave; row < rows; row += 4) {
-        const int yi = row & (BY - 1), zi = row >> a.by_log2;
-        const int y = by * BY + yi, z = bz * BZ + zi;
-        if (y >= g.ny || z >= g.nz) continue; // wave-uniform
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        // tables of brick t+2 (read after the next B1)
+        int n2x = n1x, n2y = n1y, n2z = n1z;
+        next_brick(n2x, n2y, n2z);
+        if (item + 2 < item_end) fill_tables(cur, n2x, n2y, n2z);
+
+        // ---- phase C: x from a 4-wide window of R, one float4 per lane per row --------------------
+        {
+            const int y_base = by * kBrickY, z_base = bz * BZ;
+            const bool full = (y_base + kBrickY <= g.ny) && (z_base + BZ <= g.nz) &&
+                              (bx * kBrickX + kBrickX <= g.nx) && a.vec4_ok;
+            const float *Rl[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const float *R = lds + a.band[b].r_off + row * RS[b] + (wmid0[b] - 1 - ix0[b]);
-            const float v0 = R[0], v1 = R[1], v2 = R[2], v3 = R[3];
+            for (int b = 0; b < NB; ++b) Rl[b] = lds + a.band[b].r_off + wbase[b] + wave * rs_[b];
+            auto row_values = [&](float acc[4]) {
+                acc[0] = acc[1] = acc[2] = acc[3] = 0.0f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float t = ww[b][q][0] * v0;
-                t = __builtin_fmaf(ww[b][q][1], v1, t);
-                t = __builtin_fmaf(ww[b][q][2], v2, t);
-                t = __builtin_fmaf(ww[b][q][3], v3, t);
-                if (NB == 1) acc[q] = t;
-                else acc[q] = __builtin_fmaf(a.band[b].weight, t, acc[q]);
+                for (int b = 0; b < NB; ++b) {
+                    const float v0 = Rl[b][0], v1 = Rl[b][1], v2 = Rl[b][2], v3 = Rl[b][3];
+                    Rl[b] += 4 * rs_[b];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float t = ww[b][q][0] * v0;
+                        t = __builtin_fmaf(ww[b][q][1], v1, t);
+                        t = __builtin_fmaf(ww[b][q][2], v2, t);
+                        t = __builtin_fmaf(ww[b][q][3], v3, t);
+                        if (NB == 1) acc[q] = t;
+                        else acc[q] = __builtin_fmaf(a.band[b].weight, t, acc[q]);
+                    }
+                }
+                if (NB > 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = (acc[q] / a.out_div) * g.out_scale;
+                }
+            };
+            // first row of this wave; rows of a wave are 4 apart: y advances by 4, z every other step
+            if (full) {
+                // interior brick: every wave store is one 1-KiB global_store_dwordx4
+                for (int row = wave; row < rows; row += 4) {
+                    const int y = y_base + (row & (kBrickY - 1)), z = z_base + (row >> 3);
+                    float acc[4];
+                    row_values(acc);
+                    v4f *rowp = reinterpret_cast<v4f *>(a.out + ((size_t)z * g.ny + y) * g.nx +
+                                                        (size_t)bx * kBrickX); // wave-uniform
+                    rowp[lane] = v4f{acc[0], acc[1], acc[2], acc[3]};
+                }
+            } else {
+                for (int row = wave; row < rows; row += 4) {
+                    const int y = y_base + (row & (kBrickY - 1)), z = z_base + (row >> 3);
+                    float acc[4];
+                    row_values(acc);
+                    if (y < g.ny && z < g.nz) {
+                        float *dst = a.out + ((size_t)z * g.ny + y) * g.nx + x0;
+                        if (a.vec4_ok && x0 + 3 < g.nx) {
+                            *reinterpret_cast<v4f *>(dst) = v4f{acc[0], acc[1], acc[2], acc[3]};
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (x0 + q < g.nx) dst[q] = acc[q];
+                        }
+                    }
+                }
             }
         }
-        if (NB > 1) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = (acc[q] / a.out_div) * g.out_scale;
-        }
-        if (!lane_in) continue;
-        float *dst = a.out + ((size_t)z * g.ny + y) * g.nx + x0;
-        if (a.vec4_ok && x0 + 3 < g.nx) {
-            *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (x0 + q < g.nx) dst[q] = acc[q];
+
+        if (!has_next) break;
+        ++item;
+        bx = n1x; by = n1y; bz = n1z;
+        n1x = n2x; n1y = n2y; n1z = n2z;
+        cur ^= 1;
+        if (bx != weights_bx) { // tables[cur] of the new brick have been visible since the last B1
+            x_weights(cur);
+            weights_bx = bx;
         }
     }
 }
@@ -364,13 +502,14 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
               const float *weights, SepArgs *a, size_t *lds_bytes)
 {
     if (tile->n == 0 || nbands < 1 || nbands > kMaxBands) return false;
+    if (pow2_mask(tile->n) < 0) return false; // the brick kernel wraps with a mask: power-of-two tiles
     if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0) return false;
     const int BZ = g.nz >= kMaxBZ ? kMaxBZ : ceil_pow2(g.nz);
-    const int BY = (BZ == kMaxBZ) ? kMaxRows / kMaxBZ : kMaxBY;
-    const int rows = BY * BZ;
+    const int rows = kBrickY * BZ;
     const double zmax = g.z_const_mode ? 0.0 : (double)g.z0 + g.nz;
     const double imax = fmax(fmax((double)g.nx, (double)g.ny), zmax);
-    size_t off = 0;
+    size_t box_total = 0, r_total = 0;
+    int exs[kMaxBands];
     for (int b = 0; b < nbands; ++b) {
         const double step = (double)g.base_range * (double)oscale[b] * (double)g.post_scale / g.den;
         if (!(step >= 0.0) || !std::isfinite(step)) return false;
@@ -379,20 +518,25 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
         const double slack = pmax * 4.8e-7; // 4 ulp of the largest coordinate
         if (3.0 * step + slack > 1.0) return false; // 4 consecutive samples span <= 2 mids
         auto extent = [&](int samples) { return (int)floor((samples - 1) * step + slack) + 1 + 3; };
-        const int ex = extent(kBrickX) + 1, ey = extent(BY), ez = g.z_const_mode ? 3 : extent(BZ);
+        exs[b] = extent(kBrickX) + 1;
+        if (extent(kBrickY) > kBoxY || (!g.z_const_mode && extent(BZ) > kBoxZ)) return false;
         a->band[b].oscale = oscale[b];
         a->band[b].weight = weights ? weights[b] : 1.0f;
-        a->band[b].box_off = (int)off;
-        off += (size_t)ex * ey * ez;
-        a->band[b].r_off = (int)off;
-        off += (size_t)rows * (ex | 1) + 4;
+        a->band[b].box_off = (int)box_total;
+        box_total += (size_t)exs[b] * kColStride;
     }
+    a->box_buf_stride = (int)box_total;
+    size_t off = 2 * box_total; // two copies of every band's box, then the R rows
+    for (int b = 0; b < nbands; ++b) {
+        a->band[b].r_off = (int)(off + r_total);
+        r_total += (size_t)rows * (exs[b] | 1) + 4;
+    }
+    off += r_total;
     *lds_bytes = off * sizeof(float);
     if (*lds_bytes > 60 * 1024) return false;
-    a->by_log2 = __builtin_ctz(BY);
     a->bz_log2 = __builtin_ctz(BZ);
     a->nbx = (g.nx + kBrickX - 1) / kBrickX;
-    a->nby = (g.ny + BY - 1) / BY;
+    a->nby = (g.ny + kBrickY - 1) / kBrickY;
     a->nbz = (g.nz + BZ - 1) / BZ;
     const long long blocks = (long long)a->nbx * a->nby * a->nbz;
     if (blocks > 0x7fffffffLL) return false;
@@ -405,10 +549,47 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
     return true;
 }
 
+int compute_units()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// Persistent grid: k workgroups per CU, k chosen (within what LDS and the 32-wave limit admit)
+// so that the bricks divide as evenly as possible over the workgroups.
+int persistent_grid(long long items, size_t lds_bytes)
+{
+    const int cus = compute_units();
+    int kmax = (int)((160 * 1024) / (lds_bytes + 2048));
+    kmax = kmax > 8 ? 8 : (kmax < 1 ? 1 : kmax);
+    if (const char *e = getenv("WN_WGS_PER_CU")) { // DEV ONLY
+        const int k = atoi(e);
+        if (k >= 1 && k <= 8) return (int)std::min<long long>(items, (long long)cus * k);
+    }
+    int best_k = kmax;
+    double best_eff = -1.0;
+    for (int k = kmax; k >= (kmax > 4 ? 4 : 1); --k) {
+        const long long wgs = (long long)cus * k;
+        if (items <= wgs) return (int)items;
+        const long long per = (items + wgs - 1) / wgs;
+        const double eff = (double)items / (double)(per * wgs) * (0.9 + 0.0125 * k); // mild preference for occupancy
+        if (eff > best_eff) { best_eff = eff; best_k = k; }
+    }
+    return (int)std::min<long long>(items, (long long)cus * best_k);
+}
+
 template <int NB>
 void launch_sep(const SepArgs &a, size_t lds, hipStream_t s)
 {
-    hipLaunchKernelGGL(grid3d_sep_kernel<NB>, dim3(a.nbx * a.nby * a.nbz), dim3(256), lds, s, a);
+    const long long items = (long long)a.nbx * a.nby * a.nbz;
+    hipLaunchKernelGGL(grid3d_sep_kernel<NB>, dim3(persistent_grid(items, lds)), dim3(256), lds, s, a);
 }
 
 int run_sep(const SepArgs &a, size_t lds, hipStream_t s)
