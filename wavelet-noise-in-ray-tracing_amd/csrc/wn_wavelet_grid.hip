@@ -34,13 +34,11 @@ using wn::GridArgs;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxBands = 8;
-constexpr int kBrickX = 256;  // samples per brick along x (64 lanes x 4)
 constexpr int kBrickY = 8;    // sample rows per brick along y
 constexpr int kMaxBZ = 8;     // ... and along z (power of two <= 8, fewer for thin slabs)
 constexpr int kBoxY = 6;      // coefficient box: at most 6 rows in y and in z (8 samples, step <= 1/3)
 constexpr int kBoxZ = 6;
 constexpr int kColStride = kBoxY * kBoxZ + 1; // LDS floats per box column (odd: conflict-free fills)
-constexpr int kPrefetch = 8;  // coefficient-box values a lane keeps in flight per band
 
 struct BandArgs {
     float oscale; // octave_scale of this band
@@ -56,11 +54,13 @@ struct SepArgs {
     GridArgs g;
     int bz_log2;
     int box_buf_stride; // floats between the two copies of the box region (double buffering)
+    int r_buf_stride;   // ... and of the R region (single band only, else 0)
     int nbx, nby, nbz;
     int nbands;
     float out_div;
     float inv_den; // 1/den when den is a power of two (exact), else 0
     int vec4_ok;
+    int xw; // wave columns per brick (1 or 2)
     BandArgs band[kMaxBands];
 };
 
@@ -96,17 +96,22 @@ __device__ __forceinline__ float lattice_coord_fast(int i, float den, float inv_
 //     box[i][k][j]  column-major coefficient box, i = x column, fixed strides (kColStride, kBoxY)
 //                   so that a row's 9 (k,j) taps are immediate offsets from one address;
 //     R[row][i]     collapsed rows, odd row stride.
-template <int NB>
-__global__ __launch_bounds__(256) void grid3d_sep_kernel(const SepArgs a)
+// XW = wave columns per brick: the brick is XW*256 samples wide and the workgroup has 4*XW waves;
+// wave (xw, wr) = (wave / 4, wave % 4) stores rows wr, wr+4, ... of the xw-th 256-sample column, so
+// with XW = 2 the two halves of a 2-KiB output row are written by sibling waves at the same time.
+template <int NB, int XW>
+__global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
 {
     extern __shared__ float lds[];
-    // per-band sample tables, double buffered: slots 0..7 y samples, 8..15 z samples,
+    // per-band sample tables, triple buffered: slots 0..7 y samples, 8..15 z samples,
     // 16/17 first/last x sample of the brick
-    __shared__ int s_mid[2][NB][32];
-    __shared__ float s_w[2][NB][16][3];
+    __shared__ int s_mid[3][NB][32];
+    __shared__ float s_w[3][NB][16][3];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kWaves = 4 * XW, kBrickX = 256 * XW;
+    const int xw = wave >> 2, wr = wave & 3;
     const int BZ = 1 << a.bz_log2, rows = kBrickY * BZ;
     const GridArgs &g = a.g;
     const float den = (float)g.den;
@@ -146,64 +151,60 @@ __global__ __launch_bounds__(256) void grid3d_sep_kernel(const SepArgs a)
         }
     };
 
-    // coefficient-box geometry of a brick, read back from its tables (wave-uniform)
-    struct Box { int ix0, jy0, kz0, ex, ey, ez; };
+    // coefficient-box geometry of a brick, read back from its tables into SGPRs
+    struct Box { int ix0, jy0, kz0, ex, ey, nrows; };
+    auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     auto box_of = [&](int buf, int b) {
         Box o;
-        o.ix0 = s_mid[buf][b][16] - 1;
-        o.ex = s_mid[buf][b][17] - s_mid[buf][b][16] + 4; // +3 support, +1 pad column (zero-weight tap)
-        o.jy0 = s_mid[buf][b][0] - 1;
-        o.ey = s_mid[buf][b][kBrickY - 1] - s_mid[buf][b][0] + 3;
-        o.kz0 = s_mid[buf][b][8] - 1;
-        o.ez = s_mid[buf][b][8 + BZ - 1] - s_mid[buf][b][8] + 3;
+        const int mx0 = sgpr(s_mid[buf][b][16]), mx1 = sgpr(s_mid[buf][b][17]);
+        const int my0 = sgpr(s_mid[buf][b][0]), my1 = sgpr(s_mid[buf][b][kBrickY - 1]);
+        const int mz0 = sgpr(s_mid[buf][b][8]), mz1 = sgpr(s_mid[buf][b][8 + BZ - 1]);
+        o.ix0 = mx0 - 1;
+        o.ex = mx1 - mx0 + 4; // +3 support, +1 pad column (zero-weight tap)
+        o.jy0 = my0 - 1;
+        o.ey = my1 - my0 + 3;
+        o.kz0 = mz0 - 1;
+        o.nrows = (mz1 - mz0 + 3) * o.ey;
         return o;
     };
 
-    // this lane's share of a band's box: element e = tid + 256*u, e = (k*ey + j)*ex + i (i fastest:
-    // coalesced global reads, conflict-free LDS fills thanks to the odd column stride)
-    float pf[NB][kPrefetch];
-    auto box_element = [&](const Box &o, int e, float inv_ex, float inv_ey, int &lds_idx) {
-        const int r = (int)(((float)e + 0.5f) * inv_ex), i = e - r * o.ex;
-        const int k = (int)(((float)r + 0.5f) * inv_ey), j = r - k * o.ey;
-        lds_idx = i * kColStride + k * kBoxY + j;
-        return (((o.kz0 + k) & a.nmask) * a.n + ((o.jy0 + j) & a.nmask)) * a.n + ((o.ix0 + i) & a.nmask);
-    };
-    auto issue_box = [&](int buf) {
+    // Box rows are (k, j) pairs, r = k*ey + j; wave w takes rows w, w+4, ...: the row part of every
+    // address is scalar, a lane contributes only its column.  Columns 0..63 in `pf`, the (at most
+    // 27) columns from 64 on in `pfx`.
+    constexpr int kRowsPerWave = (kBoxY * kBoxZ + kWaves - 1) / kWaves;
+    constexpr int kColGroups = (kBrickX / 3 + 8 + 63) / 64; // 64-column groups a box can span (step <= 1/3)
+    float pf[kRowsPerWave][kColGroups];
+    auto issue_box = [&](int buf, int b) {
+        const Box o = box_of(buf, b);
+        int k = 0, j = wave;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const Box o = box_of(buf, b);
-            const int count = o.ez * o.ey * o.ex;
-            const float inv_ex = 1.0f / (float)o.ex, inv_ey = 1.0f / (float)o.ey;
+        for (int t = 0; t < kRowsPerWave; ++t) {
+            while (j >= o.ey) { j -= o.ey; ++k; }
+            const bool row_on = wave + kWaves * t < o.nrows;
+            const float *row = a.coef + (((o.kz0 + k) & a.nmask) * a.n + ((o.jy0 + j) & a.nmask)) * a.n;
 #pragma unroll
-            for (int u = 0; u < kPrefetch; ++u) {
-                const int e = tid + 256 * u;
-                int unused;
-                pf[b][u] = (e < count) ? a.coef[box_element(o, e, inv_ex, inv_ey, unused)] : 0.0f;
+            for (int c = 0; c < kColGroups; ++c) {
+                pf[t][c] = 0.0f;
+                if (row_on && 64 * c < o.ex && lane + 64 * c < o.ex)
+                    pf[t][c] = row[(o.ix0 + 64 * c + lane) & a.nmask];
             }
+            j += kWaves;
         }
     };
-    auto commit_box = [&](int buf, int box_buf) {
+    auto commit_box = [&](int buf, int b, int box_buf) {
+        const Box o = box_of(buf, b);
+        float *col = lds + a.band[b].box_off + box_buf * a.box_buf_stride + lane * kColStride;
+        int k = 0, j = wave;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const Box o = box_of(buf, b);
-            const int count = o.ez * o.ey * o.ex;
-            const float inv_ex = 1.0f / (float)o.ex, inv_ey = 1.0f / (float)o.ey;
-            float *box = lds + a.band[b].box_off + box_buf * a.box_buf_stride;
+        for (int t = 0; t < kRowsPerWave; ++t) {
+            while (j >= o.ey) { j -= o.ey; ++k; }
+            if (wave + kWaves * t < o.nrows) {
+                const int at = k * kBoxY + j;
 #pragma unroll
-            for (int u = 0; u < kPrefetch; ++u) {
-                const int e = tid + 256 * u;
-                if (e < count) {
-                    int at;
-                    box_element(o, e, inv_ex, inv_ey, at);
-                    box[at] = pf[b][u];
-                }
+                for (int c = 0; c < kColGroups; ++c)
+                    if (64 * c < o.ex && lane + 64 * c < o.ex) col[64 * c * kColStride + at] = pf[t][c];
             }
-            // boxes larger than the prefetch window (steps near 1/3): the rest synchronously
-            for (int e = tid + 256 * kPrefetch; e < count; e += 256) {
-                int at;
-                const int src = box_element(o, e, inv_ex, inv_ey, at);
-                box[at] = a.coef[src];
-            }
+            j += kWaves;
         }
     };
 
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void grid3d_sep_kernel(const SepArgs a)
     int wbase[NB];
     int x0 = 0;
     auto x_weights = [&](int buf) {
-        x0 = bx * kBrickX + lane * 4;
+        x0 = bx * kBrickX + xw * 256 + lane * 4;
         float xbase[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -242,55 +243,33 @@ __global__ __launch_bounds__(256) void grid3d_sep_kernel(const SepArgs a)
         }
     };
 
-    // ---- pipeline ---------------------------------------------------------------------------------
-    // Tables and the coefficient box are double buffered (index = brick parity).  While brick t
-    // runs phase 1 out of box[t&1], the loads of box[(t+1)&1] are in flight; they are committed to
-    // LDS before barrier B2, i.e. BEFORE brick t's stores are issued, so the vmcnt wait that
-    // retires them only has the previous brick's (long finished) stores ahead of it.
-    auto next_brick = [&](int &nx_, int &ny_, int &nz_) {
-        if (++ny_ == a.nby) { ny_ = 0; ++nz_; }
-        if (nz_ == a.nbz) { nz_ = 0; ++nx_; }
-    };
-    int cur = 0;
-    fill_tables(0, bx, by, bz);
-    int n1x = bx, n1y = by, n1z = bz; // brick t+1
-    next_brick(n1x, n1y, n1z);
-    if (item + 1 < item_end) fill_tables(1, n1x, n1y, n1z);
-    __syncthreads();
-    issue_box(0);
-    commit_box(0, 0);
-    x_weights(0);
-    int weights_bx = bx;
+    // ---- phases ------------------------------------------------------------------------------------
+    int rs_[NB]; // R row strides of the brick in flight (odd: conflict-free column writes)
 
-    for (;;) {
-        const bool has_next = item + 1 < item_end;
-        __syncthreads(); // B1: previous phase C done (R free); tables of brick t+1 visible; box[cur] complete
-
-        if (has_next) issue_box(cur ^ 1); // in flight during phase 1
-
-        // ---- phase 1: collapse y and z.  Lane = sample row (its 9 yz-weights in registers),
-        //      the 4 waves split the coefficient columns:
-        //      R[row][i] = out_scale * sum_k sum_j (wz[k]*wy[j]) * C[kz+k][jy+j][i]
-        int rs_[NB];
+    // phase 1: collapse y and z.  Lane = sample row (its 9 yz-weights in registers), the waves
+    // split the coefficient columns:
+    //     R[row][i] = out_scale * sum_k sum_j (wz[k]*wy[j]) * C[kz+k][jy+j][i]
+    auto phase1 = [&](int tb, int box_buf, int r_buf) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) rs_[b] = (s_mid[cur][b][17] - s_mid[cur][b][16] + 4) | 1;
+        for (int b = 0; b < NB; ++b)
+            rs_[b] = (sgpr(s_mid[tb][b][17]) - sgpr(s_mid[tb][b][16]) + 4) | 1;
         if (lane < rows) {
             const int yi = lane & (kBrickY - 1), zi = lane >> 3;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const int ex = s_mid[cur][b][17] - s_mid[cur][b][16] + 4;
-                const int kz = s_mid[cur][b][8 + zi] - s_mid[cur][b][8];  // row's first box row in z
-                const int jy = s_mid[cur][b][yi] - s_mid[cur][b][0];      // ... and in y
+                const int ex = sgpr(s_mid[tb][b][17]) - sgpr(s_mid[tb][b][16]) + 4;
+                const int kz = s_mid[tb][b][8 + zi] - s_mid[tb][b][8];  // row's first box row in z
+                const int jy = s_mid[tb][b][yi] - s_mid[tb][b][0];      // ... and in y
                 float w9[3][3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) w9[k][j] = s_w[cur][b][8 + zi][k] * s_w[cur][b][yi][j];
-                const int chunk = (ex + 3) >> 2;
+                    for (int j = 0; j < 3; ++j) w9[k][j] = s_w[tb][b][8 + zi][k] * s_w[tb][b][yi][j];
+                const int chunk = (ex + kWaves - 1) / kWaves;
                 const int i_begin = wave * chunk, i_end = min(ex, i_begin + chunk);
-                const float *c = lds + a.band[b].box_off + cur * a.box_buf_stride + kz * kBoxY + jy +
+                const float *c = lds + a.band[b].box_off + box_buf * a.box_buf_stride + kz * kBoxY + jy +
                                  i_begin * kColStride;
-                float *R = lds + a.band[b].r_off + lane * rs_[b] + i_begin;
+                float *R = lds + a.band[b].r_off + r_buf * a.r_buf_stride + lane * rs_[b] + i_begin;
                 for (int i = i_begin; i < i_end; ++i, c += kColStride, ++R) {
                     float acc = w9[0][0] * c[0];
 #pragma unroll
@@ -302,61 +281,59 @@ __global__ __launch_bounds__(256) void grid3d_sep_kernel(const SepArgs a)
                 }
             }
         }
-        if (has_next) commit_box(cur ^ 1, cur ^ 1);
-        __syncthreads(); // B2: R rows and box[cur^1] complete; tables[cur] are dead
+    };
 
-        // tables of brick t+2 (read after the next B1)
-        int n2x = n1x, n2y = n1y, n2z = n1z;
-        next_brick(n2x, n2y, n2z);
-        if (item + 2 < item_end) fill_tables(cur, n2x, n2y, n2z);
-
-        // ---- phase C: x from a 4-wide window of R, one float4 per lane per row --------------------
-        {
-            const int y_base = by * kBrickY, z_base = bz * BZ;
-            const bool full = (y_base + kBrickY <= g.ny) && (z_base + BZ <= g.nz) &&
-                              (bx * kBrickX + kBrickX <= g.nx) && a.vec4_ok;
-            const float *Rl[NB];
+    // phase C: x from a 4-wide window of R, one float4 per lane per row
+    auto phaseC = [&](int r_buf) {
+        const int y_base = by * kBrickY, z_base = bz * BZ;
+        const bool full = (y_base + kBrickY <= g.ny) && (z_base + BZ <= g.nz) &&
+                          (bx * kBrickX + kBrickX <= g.nx) && a.vec4_ok;
+        const float *Rl[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) Rl[b] = lds + a.band[b].r_off + wbase[b] + wave * rs_[b];
-            auto row_values = [&](float acc[4]) {
-                acc[0] = acc[1] = acc[2] = acc[3] = 0.0f;
+        for (int b = 0; b < NB; ++b)
+            Rl[b] = lds + a.band[b].r_off + r_buf * a.r_buf_stride + wbase[b] + wr * rs_[b];
+        auto row_values = [&](float acc[4]) {
+            acc[0] = acc[1] = acc[2] = acc[3] = 0.0f;
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const float v0 = Rl[b][0], v1 = Rl[b][1], v2 = Rl[b][2], v3 = Rl[b][3];
-                    Rl[b] += 4 * rs_[b];
+            for (int b = 0; b < NB; ++b) {
+                const float v0 = Rl[b][0], v1 = Rl[b][1], v2 = Rl[b][2], v3 = Rl[b][3];
+                Rl[b] += 4 * rs_[b];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float t = ww[b][q][0] * v0;
-                        t = __builtin_fmaf(ww[b][q][1], v1, t);
-                        t = __builtin_fmaf(ww[b][q][2], v2, t);
-                        t = __builtin_fmaf(ww[b][q][3], v3, t);
-                        if (NB == 1) acc[q] = t;
-                        else acc[q] = __builtin_fmaf(a.band[b].weight, t, acc[q]);
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    float t = ww[b][q][0] * v0;
+                    t = __builtin_fmaf(ww[b][q][1], v1, t);
+                    t = __builtin_fmaf(ww[b][q][2], v2, t);
+                    t = __builtin_fmaf(ww[b][q][3], v3, t);
+                    if (NB == 1) acc[q] = t;
+                    else acc[q] = __builtin_fmaf(a.band[b].weight, t, acc[q]);
                 }
-                if (NB > 1) {
+            }
+            if (NB > 1) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = (acc[q] / a.out_div) * g.out_scale;
-                }
-            };
-            // first row of this wave; rows of a wave are 4 apart: y advances by 4, z every other step
-            if (full) {
-                // interior brick: every wave store is one 1-KiB global_store_dwordx4
-                for (int row = wave; row < rows; row += 4) {
-                    const int y = y_base + (row & (kBrickY - 1)), z = z_base + (row >> 3);
-                    float acc[4];
-                    row_values(acc);
-                    v4f *rowp = reinterpret_cast<v4f *>(a.out + ((size_t)z * g.ny + y) * g.nx +
-                                                        (size_t)bx * kBrickX); // wave-uniform
-                    rowp[lane] = v4f{acc[0], acc[1], acc[2], acc[3]};
-                }
-            } else {
-                for (int row = wave; row < rows; row += 4) {
-                    const int y = y_base + (row & (kBrickY - 1)), z = z_base + (row >> 3);
+                for (int q = 0; q < 4; ++q) acc[q] = (acc[q] / a.out_div) * g.out_scale;
+            }
+        };
+        // A wave owns rows wr, wr+4, ...: per z plane the y rows (wr) and (wr + 4).
+        const size_t plane = (size_t)g.ny * g.nx;
+        float *zrow = a.out + ((size_t)z_base * g.ny + y_base + wr) * g.nx + (size_t)bx * kBrickX + xw * 256;
+        if (full) {
+            // interior brick: every wave store is one 1-KiB global_store_dwordx4
+            for (int zi = 0; zi < BZ; ++zi, zrow += plane) {
+                float acc[4];
+                row_values(acc);
+                reinterpret_cast<v4f *>(zrow)[lane] = v4f{acc[0], acc[1], acc[2], acc[3]};
+                row_values(acc);
+                reinterpret_cast<v4f *>(zrow + 4 * (size_t)g.nx)[lane] = v4f{acc[0], acc[1], acc[2], acc[3]};
+            }
+        } else {
+            for (int zi = 0; zi < BZ; ++zi, zrow += plane) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int y = y_base + wr + 4 * h, z = z_base + zi;
                     float acc[4];
                     row_values(acc);
                     if (y < g.ny && z < g.nz) {
-                        float *dst = a.out + ((size_t)z * g.ny + y) * g.nx + x0;
+                        float *dst = zrow + (size_t)(4 * h) * g.nx + lane * 4;
                         if (a.vec4_ok && x0 + 3 < g.nx) {
                             *reinterpret_cast<v4f *>(dst) = v4f{acc[0], acc[1], acc[2], acc[3]};
                         } else {
@@ -368,14 +345,72 @@ __global__ __launch_bounds__(256) void grid3d_sep_kernel(const SepArgs a)
                 }
             }
         }
+    };
+
+    auto next_brick = [&](int &nx_, int &ny_, int &nz_) {
+        if (++ny_ == a.nby) { ny_ = 0; ++nz_; }
+        if (nz_ == a.nbz) { nz_ = 0; ++nx_; }
+    };
+
+    // ---- pipeline ---------------------------------------------------------------------------------
+    // Tables are triple buffered (brick t in slot t%3).
+    // NB == 1: R and the coefficient box are double buffered and a brick costs ONE barrier:
+    //     [issue loads of box(t+1)] [phase 1(t) -> R[t&1]] [commit box(t+1)] [tables(t+2)]
+    //     barrier
+    //     [phase C(t): R[t&1] -> stores]
+    //   The loads of brick t+1 are in flight during phase 1 and retired BEFORE brick t's stores are
+    //   issued, so the vmcnt wait that retires them only has brick t-1's stores ahead of it; waves
+    //   that finish their stores early run ahead into phase 1 of the next brick.
+    // NB > 1: single R and box (LDS and registers are the scarce resources there), boxes loaded
+    //   band by band at the top of the brick: two barriers per brick.
+    int tb = 0, par = 0;
+    fill_tables(0, bx, by, bz);
+    int n1x = bx, n1y = by, n1z = bz; // brick t+1
+    next_brick(n1x, n1y, n1z);
+    if (item + 1 < item_end) fill_tables(1, n1x, n1y, n1z);
+    __syncthreads();
+    if (NB == 1) {
+        issue_box(0, 0);
+        commit_box(0, 0, 0);
+    }
+    x_weights(0);
+    int weights_bx = bx;
+    if (NB == 1) __syncthreads();
+
+    for (;;) {
+        const bool has_next = item + 1 < item_end;
+        const int tb1 = (tb == 2) ? 0 : tb + 1, tb2 = (tb1 == 2) ? 0 : tb1 + 1;
+        int n2x = n1x, n2y = n1y, n2z = n1z; // brick t+2
+        next_brick(n2x, n2y, n2z);
+
+        if (NB == 1) {
+            if (has_next) issue_box(tb1, 0);
+            phase1(tb, par, par);
+            if (has_next) commit_box(tb1, 0, par ^ 1);
+            if (item + 2 < item_end) fill_tables(tb2, n2x, n2y, n2z);
+            __syncthreads();
+            phaseC(par);
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                issue_box(tb, b);
+                commit_box(tb, b, 0);
+            }
+            __syncthreads(); // boxes complete; previous phase C done (R free)
+            phase1(tb, 0, 0);
+            if (item + 2 < item_end) fill_tables(tb2, n2x, n2y, n2z);
+            __syncthreads(); // R complete; the boxes may be overwritten
+            phaseC(0);
+        }
 
         if (!has_next) break;
         ++item;
         bx = n1x; by = n1y; bz = n1z;
         n1x = n2x; n1y = n2y; n1z = n2z;
-        cur ^= 1;
-        if (bx != weights_bx) { // tables[cur] of the new brick have been visible since the last B1
-            x_weights(cur);
+        tb = tb1;
+        par ^= 1;
+        if (bx != weights_bx) { // tables of the new brick became visible at least one barrier ago
+            x_weights(tb);
             weights_bx = bx;
         }
     }
@@ -501,6 +536,10 @@ inline int ceil_pow2(int v)
 bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *oscale,
               const float *weights, SepArgs *a, size_t *lds_bytes)
 {
+    // two wave columns (512-sample bricks: whole 2-KiB rows written together) when the lattice is wide
+    const int xw = g.nx > 256 ? 2 : 1;
+    const int kBrickX = 256 * xw;
+    a->xw = xw;
     if (tile->n == 0 || nbands < 1 || nbands > kMaxBands) return false;
     if (pow2_mask(tile->n) < 0) return false; // the brick kernel wraps with a mask: power-of-two tiles
     if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0) return false;
@@ -525,15 +564,18 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
         a->band[b].box_off = (int)box_total;
         box_total += (size_t)exs[b] * kColStride;
     }
-    a->box_buf_stride = (int)box_total;
-    size_t off = 2 * box_total; // two copies of every band's box, then the R rows
+    // single band: two copies of box and R (one-barrier pipeline); several bands: one copy each
+    const int copies = nbands == 1 ? 2 : 1;
+    a->box_buf_stride = nbands == 1 ? (int)box_total : 0;
+    size_t off = copies * box_total; // boxes first, then the R rows
     for (int b = 0; b < nbands; ++b) {
         a->band[b].r_off = (int)(off + r_total);
         r_total += (size_t)rows * (exs[b] | 1) + 4;
     }
-    off += r_total;
+    a->r_buf_stride = nbands == 1 ? (int)r_total : 0;
+    off += copies * r_total;
     *lds_bytes = off * sizeof(float);
-    if (*lds_bytes > 60 * 1024) return false;
+    if (*lds_bytes > 120 * 1024) return false;
     a->bz_log2 = __builtin_ctz(BZ);
     a->nbx = (g.nx + kBrickX - 1) / kBrickX;
     a->nby = (g.ny + kBrickY - 1) / kBrickY;
@@ -564,15 +606,12 @@ int compute_units()
 
 // Persistent grid: k workgroups per CU, k chosen (within what LDS and the 32-wave limit admit)
 // so that the bricks divide as evenly as possible over the workgroups.
-int persistent_grid(long long items, size_t lds_bytes)
+int persistent_grid(long long items, size_t lds_bytes, int xw)
 {
     const int cus = compute_units();
     int kmax = (int)((160 * 1024) / (lds_bytes + 2048));
-    kmax = kmax > 8 ? 8 : (kmax < 1 ? 1 : kmax);
-    if (const char *e = getenv("WN_WGS_PER_CU")) { // DEV ONLY
-        const int k = atoi(e);
-        if (k >= 1 && k <= 8) return (int)std::min<long long>(items, (long long)cus * k);
-    }
+    const int wave_cap = 8 / xw; // 32 waves per CU
+    kmax = kmax > wave_cap ? wave_cap : (kmax < 1 ? 1 : kmax);
     int best_k = kmax;
     double best_eff = -1.0;
     for (int k = kmax; k >= (kmax > 4 ? 4 : 1); --k) {
@@ -585,11 +624,25 @@ int persistent_grid(long long items, size_t lds_bytes)
     return (int)std::min<long long>(items, (long long)cus * best_k);
 }
 
+template <int NB, int XW>
+void launch_sep2(const SepArgs &a, size_t lds, hipStream_t s)
+{
+    const long long items = (long long)a.nbx * a.nby * a.nbz;
+    static bool big_lds_enabled = false; // dynamic LDS beyond 64 KiB needs the opt-in once per kernel
+    if (lds > 48 * 1024 && !big_lds_enabled) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&grid3d_sep_kernel<NB, XW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        big_lds_enabled = true;
+    }
+    hipLaunchKernelGGL((grid3d_sep_kernel<NB, XW>), dim3(persistent_grid(items, lds, XW)),
+                       dim3(256 * XW), lds, s, a);
+}
+
 template <int NB>
 void launch_sep(const SepArgs &a, size_t lds, hipStream_t s)
 {
-    const long long items = (long long)a.nbx * a.nby * a.nbz;
-    hipLaunchKernelGGL(grid3d_sep_kernel<NB>, dim3(persistent_grid(items, lds)), dim3(256), lds, s, a);
+    if (a.xw == 2) launch_sep2<NB, 2>(a, lds, s);
+    else launch_sep2<NB, 1>(a, lds, s);
 }
 
 int run_sep(const SepArgs &a, size_t lds, hipStream_t s)

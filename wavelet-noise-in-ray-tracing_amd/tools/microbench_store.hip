@@ -36,6 +36,47 @@ __global__ __launch_bounds__(256) void fill_bricks(float *out, int N, float v)
     }
 }
 
+// persistent variant: G workgroups, each owns a contiguous range of bricks (as grid3d_sep_kernel)
+template <bool NT>
+__global__ __launch_bounds__(256) void fill_bricks_persistent(float *out, int N, float v)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nbx = N / 256, nby = N / 8, nbz = N / 8, nyz = nby * nbz;
+    const long long T = (long long)nbx * nyz;
+    int item = (int)(T * blockIdx.x / gridDim.x);
+    const int end = (int)(T * (blockIdx.x + 1) / gridDim.x);
+    for (; item < end; ++item) {
+        const int bx = item / nyz, yz = item - bx * nyz, bz = yz / nby, by = yz - bz * nby;
+        for (int row = wave; row < 64; row += 4) {
+            const int y = by * 8 + (row & 7), z = bz * 8 + (row >> 3);
+            v4f x = v4f{v, v + row, v + 2, v + 3};
+            v4f *dst = reinterpret_cast<v4f *>(out + ((size_t)z * N + y) * N + bx * 256) + lane;
+            if (NT) __builtin_nontemporal_store(x, dst); else *dst = x;
+        }
+    }
+}
+
+// generic persistent brick fill: brick = (XW*256) x BY x BZ samples, 4*XW waves, rows dealt to waves
+template <int XW, int BY, int BZ>
+__global__ __launch_bounds__(256 * XW) void fill_shape(float *out, int N, float v)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xw = wave >> 2, wr = wave & 3;
+    const int nbx = N / (256 * XW), nby = N / BY, nbz = N / BZ, nyz = nby * nbz;
+    const long long T = (long long)nbx * nyz;
+    int item = (int)(T * blockIdx.x / gridDim.x);
+    const int end = (int)(T * (blockIdx.x + 1) / gridDim.x);
+    for (; item < end; ++item) {
+        const int bx = item / nyz, yz = item - bx * nyz, bz = yz / nby, by = yz - bz * nby;
+        for (int row = wr; row < BY * BZ; row += 4) {
+            const int y = by * BY + (row % BY), z = bz * BZ + (row / BY);
+            v4f x = v4f{v, v + row, v + 2, v + 3};
+            v4f *dst = reinterpret_cast<v4f *>(out + ((size_t)z * N + y) * N + bx * 256 * XW + xw * 256) + lane;
+            *dst = x;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void copy_linear(const float4 *in, float4 *out, size_t n4)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = in[i];
@@ -73,6 +114,24 @@ int main()
     }
     report("fill_bricks plain", time_it([&] { fill_bricks<false><<<(N / 256) * (N / 8) * (N / 8), 256>>>(out, N, 1.f); }, 20), bytes);
     report("fill_bricks nt", time_it([&] { fill_bricks<true><<<(N / 256) * (N / 8) * (N / 8), 256>>>(out, N, 1.f); }, 20), bytes);
+    for (int k : {1, 2, 4, 8}) {
+        char nm[64];
+        snprintf(nm, 64, "fill_bricks_persistent k=%d plain", k);
+        report(nm, time_it([&] { fill_bricks_persistent<false><<<256 * k, 256>>>(out, N, 1.f); }, 20), bytes);
+        snprintf(nm, 64, "fill_bricks_persistent k=%d nt", k);
+        report(nm, time_it([&] { fill_bricks_persistent<true><<<256 * k, 256>>>(out, N, 1.f); }, 20), bytes);
+    }
+    report("shape 256x8x8   k=2", time_it([&] { fill_shape<1, 8, 8><<<512, 256>>>(out, N, 1.f); }, 20), bytes);
+    report("shape 256x16x4  k=2", time_it([&] { fill_shape<1, 16, 4><<<512, 256>>>(out, N, 1.f); }, 20), bytes);
+    report("shape 256x32x2  k=2", time_it([&] { fill_shape<1, 32, 2><<<512, 256>>>(out, N, 1.f); }, 20), bytes);
+    report("shape 256x64x1  k=2", time_it([&] { fill_shape<1, 64, 1><<<512, 256>>>(out, N, 1.f); }, 20), bytes);
+    report("shape 512x8x8   k=1", time_it([&] { fill_shape<2, 8, 8><<<256, 512>>>(out, N, 1.f); }, 20), bytes);
+    report("shape 512x8x8   k=2", time_it([&] { fill_shape<2, 8, 8><<<512, 512>>>(out, N, 1.f); }, 20), bytes);
+    report("shape 512x32x2  k=2", time_it([&] { fill_shape<2, 32, 2><<<512, 512>>>(out, N, 1.f); }, 20), bytes);
+    report("shape 512x64x1  k=2", time_it([&] { fill_shape<2, 64, 1><<<512, 512>>>(out, N, 1.f); }, 20), bytes);
+    report("shape 512x64x1  k=1", time_it([&] { fill_shape<2, 64, 1><<<256, 512>>>(out, N, 1.f); }, 20), bytes);
+    report("shape 512x16x1  k=2", time_it([&] { fill_shape<2, 16, 1><<<512, 512>>>(out, N, 1.f); }, 20), bytes);
+    report("shape 512x16x1  k=4", time_it([&] { fill_shape<2, 16, 1><<<1024, 512>>>(out, N, 1.f); }, 20), bytes);
     report("copy_linear (read+write bytes)", time_it([&] { copy_linear<<<8192, 256>>>((const float4 *)in, (float4 *)out, n / 4); }, 20), 2.0 * bytes);
     hipMemsetAsync(out, 0, bytes);
     report("hipMemsetAsync", time_it([&] { hipMemsetAsync(out, 0, bytes); }, 20), bytes);
