@@ -58,6 +58,10 @@ WN_API int wn_device_get(int *ordinal);
 WN_API int wn_device_info(char *name, size_t name_len, int *compute_units, size_t *hbm_bytes);
 WN_API int wn_dev_alloc(void **dptr, size_t bytes);
 WN_API int wn_dev_free(void *dptr);
+/* Host memory the device can address (pinned + mapped): `*dev_alias` is the same bytes seen from
+ * kernels.  The host classes use it to run scalar value(p) calls as one launch + one sync. */
+WN_API int wn_host_alloc_mapped(void **host_ptr, void **dev_alias, size_t bytes);
+WN_API int wn_host_free_mapped(void *host_ptr);
 WN_API int wn_copy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
 WN_API int wn_copy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 WN_API int wn_stream_sync(void *stream);

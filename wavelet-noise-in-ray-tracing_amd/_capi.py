@@ -40,6 +40,8 @@ SIGNATURES = {
     "wn_device_info": (_i, [C.c_char_p, _sz, C.POINTER(C.c_int), C.POINTER(_sz)]),
     "wn_dev_alloc": (_i, [_pp, _sz]),
     "wn_dev_free": (_i, [_vp]),
+    "wn_host_alloc_mapped": (_i, [_pp, _pp, _sz]),
+    "wn_host_free_mapped": (_i, [_vp]),
     "wn_copy_h2d": (_i, [_vp, _vp, _sz, _vp]),
     "wn_copy_d2h": (_i, [_vp, _vp, _sz, _vp]),
     "wn_stream_sync": (_i, [_vp]),

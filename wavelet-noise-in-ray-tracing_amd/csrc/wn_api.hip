@@ -145,6 +145,34 @@ int wn_dev_free(void *dptr)
     return WN_OK;
 }
 
+int wn_host_alloc_mapped(void **host_ptr, void **dev_alias, size_t bytes)
+{
+    if (!host_ptr || !dev_alias) return fail(WN_ERR_INVALID, "host_ptr/dev_alias is NULL");
+    *host_ptr = *dev_alias = nullptr;
+    int rc = require_device();
+    if (rc) return rc;
+    if (bytes == 0) return WN_OK;
+    hipError_t e = hipHostMalloc(host_ptr, bytes, hipHostMallocMapped);
+    if (e != hipSuccess) {
+        hip_fail(e, "hipHostMalloc");
+        return WN_ERR_ALLOC;
+    }
+    e = hipHostGetDevicePointer(dev_alias, *host_ptr, 0);
+    if (e != hipSuccess) {
+        (void)hipHostFree(*host_ptr);
+        *host_ptr = nullptr;
+        return hip_fail(e, "hipHostGetDevicePointer");
+    }
+    return WN_OK;
+}
+
+int wn_host_free_mapped(void *host_ptr)
+{
+    if (!host_ptr) return WN_OK;
+    WN_HIP(hipHostFree(host_ptr));
+    return WN_OK;
+}
+
 int wn_copy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream)
 {
     if (bytes == 0) return WN_OK;

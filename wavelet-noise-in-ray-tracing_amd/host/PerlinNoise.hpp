@@ -1,0 +1,43 @@
+// PerlinNoise.hpp -- the reference's experient/PerlinNoise.hpp:9-61 (the same improved-noise
+// algorithm as perlin.h with an explicit seed and no vec3 overloads) over the MI355X C ABI.
+#ifndef PERLINNOISE_HPP
+#define PERLINNOISE_HPP
+
+#include <random>
+#include <vector>
+
+#include "wn_host.hpp"
+
+class PerlinNoise {
+  private:
+    std::vector<int> p;
+    wn_perm *perm_ = nullptr;
+
+  public:
+    explicit PerlinNoise(unsigned int seed = std::mt19937::default_seed) : p(512)
+    {
+        wnhost::check(wn_perm_create_seeded(seed, &perm_), "wn_perm_create_seeded");
+        wnhost::check(wn_perm_download(perm_, p.data()), "wn_perm_download");
+    }
+    ~PerlinNoise() { wn_perm_destroy(perm_); }
+    PerlinNoise(const PerlinNoise &) = delete;
+    PerlinNoise &operator=(const PerlinNoise &) = delete;
+
+    double noise(double x, double y, double z) const // PerlinNoise.hpp:36-56
+    {
+        auto &s = wnhost::Scratch::get();
+        s.in_host64()[0] = x;
+        s.in_host64()[1] = y;
+        s.in_host64()[2] = z;
+        wnhost::check(wn_perlin_points(perm_, static_cast<const double *>(s.in_dev()), 1,
+                                       static_cast<double *>(s.out_dev()), nullptr), "wn_perlin_points");
+        wnhost::check(wn_stream_sync(nullptr), "wn_stream_sync");
+        return s.out_host64()[0];
+    }
+    double noise(double x, double y) const { return noise(x, y, 0.0); } // PerlinNoise.hpp:58-60
+
+    const std::vector<int> &table() const { return p; }
+    const wn_perm *perm() const { return perm_; }
+};
+
+#endif

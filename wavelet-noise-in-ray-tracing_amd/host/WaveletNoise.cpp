@@ -1,0 +1,152 @@
+// WaveletNoise.cpp -- host side of class WaveletNoise over libwnoise_hip.so.  No noise
+// arithmetic here: tile filtering and every evaluation are HIP kernels behind include/wnoise.h.
+#include "WaveletNoise.h"
+
+#include <algorithm>
+#include <cmath>
+
+#include "wn_host.hpp"
+
+using wnhost::check;
+
+WaveletNoise::WaveletNoise(int tileSize, unsigned int seed)
+    : tileSizeN(wn_tile_even_size(tileSize)), randomSeed(seed), rng(seed), gaussianDist(0.0f, 1.0f),
+      tile_(nullptr)
+{
+    if (tileSizeN != tileSize) // WaveletNoise.cpp:22-25
+        std::cerr << "Warning: Tile size adjusted to " << tileSizeN << " (must be even)" << std::endl;
+}
+
+WaveletNoise::~WaveletNoise() { wn_tile_destroy(tile_); }
+
+void WaveletNoise::generate(int dims)
+{
+    const size_t n = static_cast<size_t>(tileSizeN);
+    const size_t count = dims == 2 ? n * n : n * n * n;
+    std::vector<float> field(count);
+    for (size_t i = 0; i < count; ++i) field[i] = gaussianDist(rng); // WaveletNoise.cpp:74-77,146-147
+    wn_tile *t = nullptr;
+    check(wn_tile_generate_from_field(tileSizeN, dims, field.data(), &t), "wn_tile_generate_from_field");
+    wn_tile_destroy(tile_);
+    tile_ = t;
+    noiseCoefficients.resize(count);
+    check(wn_tile_download(tile_, noiseCoefficients.data()), "wn_tile_download");
+}
+
+void WaveletNoise::generateNoiseTile2D() { generate(2); }
+void WaveletNoise::generateNoiseTile3D() { generate(3); }
+
+const wn_tile *WaveletNoise::tile(int dims) const
+{
+    if (!tile_) check(wn_tile_create(0, dims, nullptr, &tile_), "wn_tile_create"); // empty: evaluates to 0
+    return tile_;
+}
+
+// ---- scalar members: a batch of one through the mapped scratch ------------------------------------
+float WaveletNoise::evaluate2D(const float p[2]) const
+{
+    auto &s = wnhost::Scratch::get();
+    s.in_host()[0] = p[0];
+    s.in_host()[1] = p[1];
+    check(wn_eval2d_points(tile(2), static_cast<const float *>(s.in_dev()), 1,
+                           static_cast<float *>(s.out_dev()), nullptr), "wn_eval2d_points");
+    check(wn_stream_sync(nullptr), "wn_stream_sync");
+    return s.out_host()[0];
+}
+
+float WaveletNoise::evaluate3D(const float p[3]) const
+{
+    auto &s = wnhost::Scratch::get();
+    std::copy(p, p + 3, s.in_host());
+    check(wn_eval3d_points(tile(3), static_cast<const float *>(s.in_dev()), 1,
+                           static_cast<float *>(s.out_dev()), nullptr), "wn_eval3d_points");
+    check(wn_stream_sync(nullptr), "wn_stream_sync");
+    return s.out_host()[0];
+}
+
+float WaveletNoise::evaluate3DProjected(const float p[3], const float normal[3]) const
+{
+    auto &s = wnhost::Scratch::get();
+    std::copy(p, p + 3, s.in_host());
+    std::copy(normal, normal + 3, s.in_host() + 4);
+    const float *in = static_cast<const float *>(s.in_dev());
+    check(wn_eval3d_projected_points(tile(3), in, in + 4, 1, static_cast<float *>(s.out_dev()), nullptr),
+          "wn_eval3d_projected_points");
+    check(wn_stream_sync(nullptr), "wn_stream_sync");
+    return s.out_host()[0];
+}
+
+float WaveletNoise::WMultibandNoise(const float p[3], float sarg, int firstBand, int nbands,
+                                    const float *w, float variance) const
+{
+    auto &s = wnhost::Scratch::get();
+    std::copy(p, p + 3, s.in_host());
+    check(wn_multiband3d_points(tile(3), static_cast<const float *>(s.in_dev()), 1, sarg, firstBand,
+                                nbands, w, variance, static_cast<float *>(s.out_dev()), nullptr),
+          "wn_multiband3d_points");
+    check(wn_stream_sync(nullptr), "wn_stream_sync");
+    return s.out_host()[0];
+}
+
+// ---- batched members ----------------------------------------------------------------------------------
+void WaveletNoise::evaluate2D(const float *xy, size_t n, float *out) const
+{
+    if (!n) return;
+    wnhost::DeviceBuffer in(2 * n * sizeof(float)), res(n * sizeof(float));
+    in.upload(xy);
+    check(wn_eval2d_points(tile(2), in.as<float>(), n, res.as<float>(), nullptr), "wn_eval2d_points");
+    res.download(out);
+}
+
+void WaveletNoise::evaluate3D(const float *xyz, size_t n, float *out) const
+{
+    if (!n) return;
+    wnhost::DeviceBuffer in(3 * n * sizeof(float)), res(n * sizeof(float));
+    in.upload(xyz);
+    check(wn_eval3d_points(tile(3), in.as<float>(), n, res.as<float>(), nullptr), "wn_eval3d_points");
+    res.download(out);
+}
+
+void WaveletNoise::evaluate3DProjected(const float *xyz, const float *normals, size_t n, float *out) const
+{
+    if (!n) return;
+    wnhost::DeviceBuffer in(3 * n * sizeof(float)), nr(3 * n * sizeof(float)), res(n * sizeof(float));
+    in.upload(xyz);
+    nr.upload(normals);
+    check(wn_eval3d_projected_points(tile(3), in.as<float>(), nr.as<float>(), n, res.as<float>(), nullptr),
+          "wn_eval3d_projected_points");
+    res.download(out);
+}
+
+void WaveletNoise::WMultibandNoise(const float *xyz, size_t n, float sarg, int firstBand, int nbands,
+                                   const float *w, float variance, float *out) const
+{
+    if (!n) return;
+    wnhost::DeviceBuffer in(3 * n * sizeof(float)), res(n * sizeof(float));
+    in.upload(xyz);
+    check(wn_multiband3d_points(tile(3), in.as<float>(), n, sarg, firstBand, nbands, w, variance,
+                                res.as<float>(), nullptr), "wn_multiband3d_points");
+    res.download(out);
+}
+
+// ---- debug helper (WaveletNoise.cpp:268-288; no caller in the reference; host-side statistics) --------
+DataStats WaveletNoise::calculateStats(const std::vector<float> &data, const std::string &name) const
+{
+    DataStats stats;
+    if (data.empty()) return stats;
+    double total = 0.0, total_sq = 0.0;
+    for (float v : data) {
+        total += v;
+        total_sq += static_cast<double>(v) * v;
+        stats.min_val = std::min(stats.min_val, v);
+        stats.max_val = std::max(stats.max_val, v);
+    }
+    stats.avg = static_cast<float>(total / data.size());
+    stats.var = static_cast<float>(total_sq / data.size() - static_cast<double>(stats.avg) * stats.avg);
+    std::cout << name << " stats: avg=" << stats.avg << ", var=" << stats.var
+              << ", stddev=" << std::sqrt(stats.var) << std::endl;
+    return stats;
+}
+
+const std::vector<float> &WaveletNoise::getNoiseCoefficients() const { return noiseCoefficients; }
+int WaveletNoise::getTileSize() const { return tileSizeN; }

@@ -1,0 +1,141 @@
+// texture.h -- the reference's texture adaptor (texture.h:14-115) over the MI355X C ABI.
+//
+// Same class names, constructors and `value(u, v, p)` signature, so material.h / main.cpp of the
+// reference compile against this header unchanged.  value() is one launch + one sync per call
+// and returns the reference's colour bit for bit; values() is the batched form a renderer should
+// use (hit points in, grey levels out, optional per-hit `active` bytes compacted with wavefront
+// ballots on the device).
+#ifndef TEXTURE_H
+#define TEXTURE_H
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+
+#include "WaveletNoise.h"
+#include "perlin.h"
+#include "vec3.h"
+#include "wn_host.hpp"
+
+using color = vec3;
+using point3 = vec3;
+
+class texture {
+  public:
+    virtual ~texture() = default;
+    virtual color value(double u, double v, const point3 &p) const = 0;
+};
+
+class solid_color : public texture {
+  public:
+    solid_color(const color &albedo) : albedo(albedo) {}
+    solid_color(double red, double green, double blue) : solid_color(color(red, green, blue)) {}
+    color value(double, double, const point3 &) const override { return albedo; }
+
+  private:
+    color albedo;
+};
+
+namespace wnhost {
+// grey levels for n host points through a device round trip
+template <typename Launch> inline void texture_batch(const float *xyz, const uint8_t *active, size_t n,
+                                                     float *grey, Launch launch)
+{
+    if (!n) return;
+    DeviceBuffer in(3 * n * sizeof(float)), out(n * sizeof(float));
+    in.upload(xyz);
+    out.upload(grey); // inactive points keep the caller's value
+    if (active) {
+        DeviceBuffer act(n);
+        act.upload(active);
+        launch(in.as<float>(), act.as<uint8_t>(), out.as<float>());
+        out.download(grey);
+    } else {
+        launch(in.as<float>(), static_cast<const uint8_t *>(nullptr), out.as<float>());
+        out.download(grey);
+    }
+}
+} // namespace wnhost
+
+class noise_texture : public texture {
+  public:
+    noise_texture(double scale, int octave = 4) : scale(scale), octave_level(octave) {}
+
+    color value(double, double, const point3 &p) const override // texture.h:37-43
+    {
+        auto &s = wnhost::Scratch::get();
+        s.in_host()[0] = p.x();
+        s.in_host()[1] = p.y();
+        s.in_host()[2] = p.z();
+        wnhost::check(wn_noise_texture_points(noise.perm(), scale, octave_level,
+                                              static_cast<const float *>(s.in_dev()), nullptr, 1,
+                                              static_cast<float *>(s.out_dev()), nullptr),
+                      "wn_noise_texture_points");
+        wnhost::check(wn_stream_sync(nullptr), "wn_stream_sync");
+        const float g = s.out_host()[0];
+        return color(g, g, g);
+    }
+    // additive: batched grey levels (host pointers); active == nullptr means every point
+    void values(const float *xyz, const uint8_t *active, size_t n, float *grey) const
+    {
+        wnhost::texture_batch(xyz, active, n, grey, [&](const float *in, const uint8_t *act, float *out) {
+            wnhost::check(wn_noise_texture_points(noise.perm(), scale, octave_level, in, act, n, out, nullptr),
+                          "wn_noise_texture_points");
+        });
+    }
+
+  private:
+    perlin noise; // default seed, texture.h:46
+    double scale;
+    int octave_level;
+};
+
+class wavelet_texture : public texture {
+  public:
+    wavelet_texture(double scale = 1.0, int octave = 4, bool use_3d = true)
+        : scale(scale), octave_level(octave), use_3d_noise(use_3d)
+    {
+        const int TILE_SIZE = 128;        // texture.h:55
+        const unsigned int SEED = 12345;  // texture.h:56
+        noise_2d = std::make_unique<WaveletNoise>(TILE_SIZE, SEED);
+        noise_2d->generateNoiseTile2D();
+        if (use_3d_noise) {
+            noise_3d = std::make_unique<WaveletNoise>(TILE_SIZE, SEED);
+            noise_3d->generateNoiseTile3D();
+        }
+    }
+
+    color value(double, double, const point3 &p) const override // texture.h:67-107
+    {
+        auto &s = wnhost::Scratch::get();
+        s.in_host()[0] = p.x();
+        s.in_host()[1] = p.y();
+        s.in_host()[2] = p.z();
+        const bool three = use_3d_noise && noise_3d;
+        wnhost::check(wn_wavelet_texture_points(source(three), three ? 1 : 0, scale, octave_level,
+                                                static_cast<const float *>(s.in_dev()), nullptr, 1,
+                                                static_cast<float *>(s.out_dev()), nullptr),
+                      "wn_wavelet_texture_points");
+        wnhost::check(wn_stream_sync(nullptr), "wn_stream_sync");
+        const float g = s.out_host()[0];
+        return color(g, g, g);
+    }
+    void values(const float *xyz, const uint8_t *active, size_t n, float *grey) const
+    {
+        const bool three = use_3d_noise && noise_3d;
+        wnhost::texture_batch(xyz, active, n, grey, [&](const float *in, const uint8_t *act, float *out) {
+            wnhost::check(wn_wavelet_texture_points(source(three), three ? 1 : 0, scale, octave_level, in,
+                                                    act, n, out, nullptr), "wn_wavelet_texture_points");
+        });
+    }
+
+  private:
+    const wn_tile *source(bool three) const { return three ? noise_3d->tile(3) : noise_2d->tile(2); }
+    std::unique_ptr<WaveletNoise> noise_2d;
+    std::unique_ptr<WaveletNoise> noise_3d;
+    double scale;
+    int octave_level;
+    bool use_3d_noise;
+};
+
+#endif

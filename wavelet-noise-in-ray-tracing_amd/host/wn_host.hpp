@@ -1,0 +1,74 @@
+// wn_host.hpp -- glue shared by the host classes: error translation and the per-thread scratch
+// that turns a scalar value(p) call into one kernel launch + one stream sync through the C ABI.
+//
+// There is no CPU arithmetic in the host classes: every evaluation, scalar or batched, runs on
+// the GPU through libwnoise_hip.so (include/wnoise.h).  A failing ABI call (most commonly: no
+// HIP device) throws std::runtime_error with wn_last_error(); nothing falls back to the CPU.
+#pragma once
+
+#include <cstddef>
+#include <stdexcept>
+#include <string>
+
+#include "wnoise.h"
+
+namespace wnhost {
+
+inline void check(int rc, const char *what)
+{
+    if (rc != WN_OK) throw std::runtime_error(std::string(what) + ": " + wn_last_error());
+}
+
+// Pinned, device-mapped staging for scalar calls: the kernel reads the point from and writes
+// the result to host memory, so a scalar call is launch + sync, with no memcpy calls.
+class Scratch {
+  public:
+    static Scratch &get()
+    {
+        thread_local Scratch s;
+        return s;
+    }
+    float *in_host() { return reinterpret_cast<float *>(host_); }
+    double *in_host64() { return reinterpret_cast<double *>(host_); }
+    float *out_host() { return reinterpret_cast<float *>(host_ + kIn); }
+    double *out_host64() { return reinterpret_cast<double *>(host_ + kIn); }
+    void *in_dev() { return dev_; }
+    void *out_dev() { return dev_ + kIn; }
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+
+  private:
+    static constexpr size_t kIn = 64, kBytes = 128;
+    Scratch()
+    {
+        void *h = nullptr, *d = nullptr;
+        check(wn_host_alloc_mapped(&h, &d, kBytes), "wn_host_alloc_mapped");
+        host_ = static_cast<char *>(h);
+        dev_ = static_cast<char *>(d);
+    }
+    ~Scratch() { wn_host_free_mapped(host_); }
+    char *host_ = nullptr, *dev_ = nullptr;
+};
+
+// Device buffer for the batched host-pointer overloads.
+class DeviceBuffer {
+  public:
+    explicit DeviceBuffer(size_t bytes) : bytes_(bytes) { check(wn_dev_alloc(&p_, bytes), "wn_dev_alloc"); }
+    ~DeviceBuffer() { wn_dev_free(p_); }
+    void *get() const { return p_; }
+    template <typename T> T *as() const { return static_cast<T *>(p_); }
+    void upload(const void *src) { check(wn_copy_h2d(p_, src, bytes_, nullptr), "wn_copy_h2d"); }
+    void download(void *dst) const
+    {
+        check(wn_copy_d2h(dst, p_, bytes_, nullptr), "wn_copy_d2h");
+        check(wn_stream_sync(nullptr), "wn_stream_sync");
+    }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+
+  private:
+    void *p_ = nullptr;
+    size_t bytes_;
+};
+
+} // namespace wnhost

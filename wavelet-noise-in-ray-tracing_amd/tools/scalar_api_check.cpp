@@ -1,0 +1,44 @@
+// scalar_api_check.cpp -- drives the SCALAR members of the host classes (the reference's own API:
+// evaluate2D/3D/3DProjected(p), noise(x,y,z), fractal_noise(p), texture::value(u,v,p)) on probe
+// points read from stdin and prints the results with 9/17 significant digits; tests/ compare
+// them with the reference's vectors.  Every call is a batch of one on the GPU.
+//
+// stdin: N, then N lines "x y z";  stdout: one line per point:
+//   e2d e3d e3dp(normal 0,0,1) perlin12345(x,y,z as double) fractal(vec3) tex_wavelet3d(1.0,4) tex_perlin(1.0,4)
+#include <cstdio>
+#include <iostream>
+#include <memory>
+#include <vector>
+
+#include "texture.h"
+
+int main()
+{
+    try {
+        size_t n = 0;
+        if (!(std::cin >> n)) return 2;
+        std::vector<float> pts(3 * n);
+        for (auto &v : pts) std::cin >> v;
+        WaveletNoise n2(128, 12345), n3(128, 12345), empty(128, 1);
+        n2.generateNoiseTile2D();
+        n3.generateNoiseTile3D();
+        perlin per(12345);
+        std::shared_ptr<texture> wt = std::make_shared<wavelet_texture>(1.0, 4, true);
+        std::shared_ptr<texture> pt = std::make_shared<noise_texture>(1.0, 4);
+        const float normal[3] = {0.0f, 0.0f, 1.0f};
+        for (size_t i = 0; i < n; ++i) {
+            const float *p = &pts[3 * i];
+            const point3 q(p[0], p[1], p[2]);
+            std::printf("%.9g %.9g %.9g %.17g %.17g %.9g %.9g\n", n2.evaluate2D(p), n3.evaluate3D(p),
+                        n3.evaluate3DProjected(p, normal), per.noise((double)p[0], (double)p[1], (double)p[2]),
+                        per.fractal_noise(q), wt->value(0, 0, q).x(), pt->value(0, 0, q).x());
+        }
+        // conventions: an un-generated object evaluates to 0 (WaveletNoise.cpp:112,186,219)
+        std::printf("empty %.9g %.9g\n", empty.evaluate3D(&pts[0]), empty.evaluate2D(&pts[0]));
+        std::printf("tile %d coeffs %zu\n", n3.getTileSize(), n3.getNoiseCoefficients().size());
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "scalar_api_check: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
