@@ -71,7 +71,9 @@ def main():
     for p in sorted(glob.glob(os.path.join(REF, "threejs/result_json/*.json"))):
         j = json.load(open(p))
         stats[os.path.basename(p)] = {"width": j["width"], "height": j["height"],
-                                      "original_range": j["original_range"]}
+                                      "original_range": j["original_range"],
+                                      "data_head": j["data"][:32], "data_len": len(j["data"]),
+                                      "data_sum": float(np.sum(np.array(j["data"], np.float64)))}
     json.dump(stats, open(os.path.join(GOLD, "json_stats.json"), "w"), indent=1, sort_keys=True)
 
     # ---- libstdc++ streams ----------------------------------------------------------------------

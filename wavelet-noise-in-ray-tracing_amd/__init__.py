@@ -24,6 +24,7 @@ from .noise import (  # noqa: E402
     wavelet_volume, multiband_volume, perlin_volume, turb_volume, device_info, HipTimer,
 )
 from .shard import slab_bounds, gather_volume  # noqa: E402
+from . import formats  # noqa: E402
 
 __all__ = [
     "WnError", "wn_grid", "WN_GRID_DEFAULT", "WN_GRID_EXACT", "WN_Z_CONST", "WN_Z_LATTICE",
@@ -31,5 +32,5 @@ __all__ = [
     "generate2DOctaveBandNoise", "generate3DSlicedOctaveBandNoise",
     "generate3DProjectedOctaveBandNoise", "generatePerlinNoise2D", "generatePerlinNoise3DSliced",
     "wavelet_volume", "multiband_volume", "perlin_volume", "turb_volume", "device_info",
-    "HipTimer", "slab_bounds", "gather_volume",
+    "HipTimer", "slab_bounds", "gather_volume", "formats",
 ]
