@@ -3,12 +3,31 @@
 #include "wn_internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <random>
 #include <vector>
 
 namespace wn {
+
+static char g_private_rand_state[256];
+static std::once_flag g_rand_once;
+
+RandStateGuard::RandStateGuard()
+{
+    std::call_once(g_rand_once, [] {
+        char *app = initstate(0x776e6f69u, g_private_rand_state, sizeof(g_private_rand_state));
+        setstate(app); // initstate switched to the private state: hand the caller's back
+    });
+    saved_ = setstate(g_private_rand_state);
+}
+
+RandStateGuard::~RandStateGuard()
+{
+    if (saved_) setstate(saved_);
+}
 
 static thread_local char g_err[512] = "";
 
@@ -86,6 +105,7 @@ const char *wn_version(void) { return "wnoise-hip 0.1 (gfx950)"; }
 
 int wn_device_count(int *count)
 {
+    WN_ENTRY();
     if (!count) return fail(WN_ERR_INVALID, "count is NULL");
     *count = 0;
     hipError_t e = hipGetDeviceCount(count);
@@ -98,12 +118,14 @@ int wn_device_count(int *count)
 
 int wn_device_set(int ordinal)
 {
+    WN_ENTRY();
     WN_HIP(hipSetDevice(ordinal));
     return WN_OK;
 }
 
 int wn_device_get(int *ordinal)
 {
+    WN_ENTRY();
     if (!ordinal) return fail(WN_ERR_INVALID, "ordinal is NULL");
     WN_HIP(hipGetDevice(ordinal));
     return WN_OK;
@@ -111,6 +133,7 @@ int wn_device_get(int *ordinal)
 
 int wn_device_info(char *name, size_t name_len, int *compute_units, size_t *hbm_bytes)
 {
+    WN_ENTRY();
     int rc = require_device();
     if (rc) return rc;
     int dev = 0;
@@ -125,6 +148,7 @@ int wn_device_info(char *name, size_t name_len, int *compute_units, size_t *hbm_
 
 int wn_dev_alloc(void **dptr, size_t bytes)
 {
+    WN_ENTRY();
     if (!dptr) return fail(WN_ERR_INVALID, "dptr is NULL");
     *dptr = nullptr;
     int rc = require_device();
@@ -140,6 +164,7 @@ int wn_dev_alloc(void **dptr, size_t bytes)
 
 int wn_dev_free(void *dptr)
 {
+    WN_ENTRY();
     if (!dptr) return WN_OK;
     WN_HIP(hipFree(dptr));
     return WN_OK;
@@ -147,6 +172,7 @@ int wn_dev_free(void *dptr)
 
 int wn_host_alloc_mapped(void **host_ptr, void **dev_alias, size_t bytes)
 {
+    WN_ENTRY();
     if (!host_ptr || !dev_alias) return fail(WN_ERR_INVALID, "host_ptr/dev_alias is NULL");
     *host_ptr = *dev_alias = nullptr;
     int rc = require_device();
@@ -168,6 +194,7 @@ int wn_host_alloc_mapped(void **host_ptr, void **dev_alias, size_t bytes)
 
 int wn_host_free_mapped(void *host_ptr)
 {
+    WN_ENTRY();
     if (!host_ptr) return WN_OK;
     WN_HIP(hipHostFree(host_ptr));
     return WN_OK;
@@ -175,6 +202,7 @@ int wn_host_free_mapped(void *host_ptr)
 
 int wn_copy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream)
 {
+    WN_ENTRY();
     if (bytes == 0) return WN_OK;
     if (!dst_dev || !src_host) return fail(WN_ERR_INVALID, "wn_copy_h2d: NULL pointer");
     WN_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)));
@@ -183,6 +211,7 @@ int wn_copy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream)
 
 int wn_copy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream)
 {
+    WN_ENTRY();
     if (bytes == 0) return WN_OK;
     if (!dst_host || !src_dev) return fail(WN_ERR_INVALID, "wn_copy_d2h: NULL pointer");
     WN_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
@@ -191,6 +220,7 @@ int wn_copy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream)
 
 int wn_stream_sync(void *stream)
 {
+    WN_ENTRY();
     WN_HIP(hipStreamSynchronize(as_stream(stream)));
     return WN_OK;
 }
@@ -198,6 +228,7 @@ int wn_stream_sync(void *stream)
 // ---- timers ------------------------------------------------------------------------------------
 int wn_timer_create(wn_timer **t)
 {
+    WN_ENTRY();
     if (!t) return fail(WN_ERR_INVALID, "t is NULL");
     *t = nullptr;
     int rc = require_device();
@@ -214,18 +245,21 @@ int wn_timer_create(wn_timer **t)
 }
 int wn_timer_start(wn_timer *t, void *stream)
 {
+    WN_ENTRY();
     if (!t) return fail(WN_ERR_INVALID, "timer is NULL");
     WN_HIP(hipEventRecord(t->start, as_stream(stream)));
     return WN_OK;
 }
 int wn_timer_stop(wn_timer *t, void *stream)
 {
+    WN_ENTRY();
     if (!t) return fail(WN_ERR_INVALID, "timer is NULL");
     WN_HIP(hipEventRecord(t->stop, as_stream(stream)));
     return WN_OK;
 }
 int wn_timer_elapsed_ms(wn_timer *t, float *ms)
 {
+    WN_ENTRY();
     if (!t || !ms) return fail(WN_ERR_INVALID, "timer/ms is NULL");
     WN_HIP(hipEventSynchronize(t->stop));
     WN_HIP(hipEventElapsedTime(ms, t->start, t->stop));
@@ -233,6 +267,7 @@ int wn_timer_elapsed_ms(wn_timer *t, float *ms)
 }
 void wn_timer_destroy(wn_timer *t)
 {
+    WN_ENTRY();
     if (!t) return;
     if (t->start) (void)hipEventDestroy(t->start);
     if (t->stop) (void)hipEventDestroy(t->stop);
@@ -242,6 +277,7 @@ void wn_timer_destroy(wn_timer *t)
 // ---- setup streams (host, libstdc++ <random>) ---------------------------------------------------
 int wn_gaussian_fill(uint32_t seed, size_t count, float *out_host)
 {
+    WN_ENTRY();
     if (count && !out_host) return fail(WN_ERR_INVALID, "out_host is NULL");
     std::mt19937 engine(seed);
     std::normal_distribution<float> gauss(0.0f, 1.0f);
@@ -251,6 +287,7 @@ int wn_gaussian_fill(uint32_t seed, size_t count, float *out_host)
 
 int wn_perlin_permutation(uint32_t seed, int out512_host[512])
 {
+    WN_ENTRY();
     if (!out512_host) return fail(WN_ERR_INVALID, "out512_host is NULL");
     std::vector<int> v(256);
     std::iota(v.begin(), v.end(), 0);
@@ -290,6 +327,7 @@ static int tile_alloc(int n, int dims, wn_tile **out)
 
 int wn_tile_create(int n, int dims, const float *coeffs_host, wn_tile **out)
 {
+    WN_ENTRY();
     if (!coeffs_host) n = 0; // empty tile: evaluates to 0 (WaveletNoise.cpp:112,186,219)
     if (n % 2 != 0)
         return fail(WN_ERR_INVALID, "wn_tile_create: coefficient tiles have even size (got %d)", n);
@@ -309,6 +347,7 @@ int wn_tile_create(int n, int dims, const float *coeffs_host, wn_tile **out)
 
 int wn_tile_generate_from_field(int n, int dims, const float *field_host, wn_tile **out)
 {
+    WN_ENTRY();
     if (!field_host && n > 0) return fail(WN_ERR_INVALID, "field_host is NULL");
     if (n % 2 != 0) return fail(WN_ERR_INVALID, "tile size must be even (got %d)", n);
     int rc = tile_alloc(n, dims, out);
@@ -338,6 +377,7 @@ int wn_tile_generate_from_field(int n, int dims, const float *field_host, wn_til
 
 int wn_tile_generate(int n, int dims, uint32_t seed, wn_tile **out)
 {
+    WN_ENTRY();
     if (n < 0) return fail(WN_ERR_INVALID, "tile size must be >= 0");
     if (dims != 2 && dims != 3) return fail(WN_ERR_INVALID, "dims must be 2 or 3 (got %d)", dims);
     const int even = wn_tile_even_size(n);
@@ -356,6 +396,7 @@ const float *wn_tile_device_ptr(const wn_tile *t) { return t ? t->dev : nullptr;
 
 int wn_tile_download(const wn_tile *t, float *out_host)
 {
+    WN_ENTRY();
     if (!t) return fail(WN_ERR_INVALID, "tile is NULL");
     if (!t->count) return WN_OK;
     if (!out_host) return fail(WN_ERR_INVALID, "out_host is NULL");
@@ -365,6 +406,7 @@ int wn_tile_download(const wn_tile *t, float *out_host)
 
 void wn_tile_destroy(wn_tile *t)
 {
+    WN_ENTRY();
     if (!t) return;
     if (t->dev) (void)hipFree(t->dev);
     delete t;
@@ -373,6 +415,7 @@ void wn_tile_destroy(wn_tile *t)
 // ---- permutation tables ----------------------------------------------------------------------------------
 int wn_perm_create(const int table512_host[512], wn_perm **out)
 {
+    WN_ENTRY();
     if (!out) return fail(WN_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!table512_host) return fail(WN_ERR_INVALID, "table is NULL");
@@ -400,6 +443,7 @@ int wn_perm_create(const int table512_host[512], wn_perm **out)
 
 int wn_perm_create_seeded(uint32_t seed, wn_perm **out)
 {
+    WN_ENTRY();
     int table[512];
     wn_perlin_permutation(seed, table);
     return wn_perm_create(table, out);
@@ -407,6 +451,7 @@ int wn_perm_create_seeded(uint32_t seed, wn_perm **out)
 
 int wn_perm_download(const wn_perm *p, int out512_host[512])
 {
+    WN_ENTRY();
     if (!p || !out512_host) return fail(WN_ERR_INVALID, "perm/out is NULL");
     uint8_t bytes[512];
     WN_HIP(hipMemcpy(bytes, p->dev, 512, hipMemcpyDeviceToHost));
@@ -416,6 +461,7 @@ int wn_perm_download(const wn_perm *p, int out512_host[512])
 
 void wn_perm_destroy(wn_perm *p)
 {
+    WN_ENTRY();
     if (!p) return;
     if (p->dev) (void)hipFree(p->dev);
     delete p;

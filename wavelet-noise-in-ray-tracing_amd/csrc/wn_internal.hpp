@@ -39,6 +39,23 @@ int require_device();
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// The HIP runtime draws from the C library's global rand() state while it launches kernels
+// (measured on ROCm 7.2: 100 launches shift the caller's rand() sequence).  The reference's
+// renderer is deterministic only through the unseeded global rand() (main.cpp:184-185,
+// rtweekend.h:37-40), so every ABI entry point parks the caller's random state and lets HIP
+// consume a private one; the caller's stream is exactly what it would be without the library.
+class RandStateGuard {
+  public:
+    RandStateGuard();
+    ~RandStateGuard();
+    RandStateGuard(const RandStateGuard &) = delete;
+    RandStateGuard &operator=(const RandStateGuard &) = delete;
+
+  private:
+    char *saved_;
+};
+#define WN_ENTRY() ::wn::RandStateGuard wn_rand_state_guard_
+
 #define WN_HIP(call)                                            \
     do {                                                        \
         hipError_t _e = (call);                                 \

@@ -220,43 +220,51 @@ extern "C" {
 
 int wn_perlin_grid(const wn_perm *perm, const wn_grid *g, float *out_dev, void *stream)
 {
+    WN_ENTRY();
     return perlin_grid(perm, g, kNoise, 0, out_dev, stream);
 }
 int wn_perlin_turb_grid(const wn_perm *perm, const wn_grid *g, int depth, float *out_dev,
                         void *stream)
 {
+    WN_ENTRY();
     if (depth < 0) return wn::fail(WN_ERR_INVALID, "depth must be >= 0");
     return perlin_grid(perm, g, kTurb, depth, out_dev, stream);
 }
 int wn_perlin_fractal_grid(const wn_perm *perm, const wn_grid *g, float *out_dev, void *stream)
 {
+    WN_ENTRY();
     return perlin_grid(perm, g, kFractal, 0, out_dev, stream);
 }
 int wn_perlin_points(const wn_perm *perm, const double *xyz_dev, size_t n, double *out_dev,
                      void *stream)
 {
+    WN_ENTRY();
     return perlin_points(perm, xyz_dev, nullptr, n, kNoise, 0, out_dev, stream);
 }
 int wn_perlin_points_vec3(const wn_perm *perm, const float *xyz_dev, size_t n, double *out_dev,
                           void *stream)
 {
+    WN_ENTRY();
     return perlin_points(perm, nullptr, xyz_dev, n, kNoise, 0, out_dev, stream);
 }
 int wn_perlin_turb_points(const wn_perm *perm, const float *xyz_dev, size_t n, int depth,
                           double *out_dev, void *stream)
 {
+    WN_ENTRY();
     if (depth < 0) return wn::fail(WN_ERR_INVALID, "depth must be >= 0");
     return perlin_points(perm, nullptr, xyz_dev, n, kTurb, depth, out_dev, stream);
 }
 int wn_perlin_fractal_points(const wn_perm *perm, const float *xyz_dev, size_t n, double *out_dev,
                              void *stream)
 {
+    WN_ENTRY();
     return perlin_points(perm, nullptr, xyz_dev, n, kFractal, 0, out_dev, stream);
 }
 
 int wn_noise_texture_points(const wn_perm *perm, double scale, int octave, const float *xyz_dev,
                             const uint8_t *active_dev, size_t n, float *grey_dev, void *stream)
 {
+    WN_ENTRY();
     int rc = wn::require_device();
     if (rc) return rc;
     if (!perm) return wn::fail(WN_ERR_INVALID, "perm is NULL");

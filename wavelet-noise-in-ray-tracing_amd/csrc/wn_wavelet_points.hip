@@ -214,6 +214,7 @@ extern "C" {
 int wn_eval3d_points(const wn_tile *tile, const float *xyz_dev, size_t n, float *out_dev,
                      void *stream)
 {
+    WN_ENTRY();
     int rc = require_device();
     if (rc) return rc;
     PointsArgs a{};
@@ -229,6 +230,7 @@ int wn_eval3d_points(const wn_tile *tile, const float *xyz_dev, size_t n, float 
 int wn_eval2d_points(const wn_tile *tile, const float *xy_dev, size_t n, float *out_dev,
                      void *stream)
 {
+    WN_ENTRY();
     int rc = require_device();
     if (rc) return rc;
     PointsArgs a{};
@@ -244,6 +246,7 @@ int wn_eval2d_points(const wn_tile *tile, const float *xy_dev, size_t n, float *
 int wn_eval3d_projected_points(const wn_tile *tile, const float *xyz_dev, const float *normals_dev,
                                size_t n, float *out_dev, void *stream)
 {
+    WN_ENTRY();
     int rc = require_device();
     if (rc) return rc;
     PointsArgs a{};
@@ -263,6 +266,7 @@ int wn_multiband3d_points(const wn_tile *tile, const float *xyz_dev, size_t n, f
                           int first_band, int nbands, const float *w_host, float var_per_band,
                           float *out_dev, void *stream)
 {
+    WN_ENTRY();
     int rc = require_device();
     if (rc) return rc;
     if (nbands < 0 || nbands > kMaxBands)
@@ -294,6 +298,7 @@ int wn_wavelet_texture_points(const wn_tile *tile, int use_3d, double scale, int
                               const float *xyz_dev, const uint8_t *active_dev, size_t n,
                               float *grey_dev, void *stream)
 {
+    WN_ENTRY();
     int rc = require_device();
     if (rc) return rc;
     if (n == 0) return WN_OK;
