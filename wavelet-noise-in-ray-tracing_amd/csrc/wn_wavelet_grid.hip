@@ -96,15 +96,11 @@ __device__ __forceinline__ float lattice_coord_fast(int i, float den, float inv_
 //     box[i][k][j]  column-major coefficient box, i = x column, fixed strides (kColStride, kBoxY)
 //                   so that a row's 9 (k,j) taps are immediate offsets from one address;
 //     R[row][i]     collapsed rows, odd row stride.
-// XW = wave columns per brick: the brick is XW*256 samples wide and the workgroup has 4*XW compute
-// waves; compute wave (xw, wr) = (wave / 4, wave % 4) stores rows wr, wr+4, ... of the xw-th
-// 256-sample column, so with XW = 2 the two halves of a 2-KiB output row are written by sibling
-// waves at the same time.  One more wave, the LOADER, never stores to global memory: it fetches the
-// next brick's coefficient boxes and fills the sample tables.  vmcnt retires loads and stores in
-// issue order, so a wave that both stores and loads would wait for its (HBM-throttled) stores
-// whenever it needs a loaded value; keeping the loads in their own wave decouples the two streams.
+// XW = wave columns per brick: the brick is XW*256 samples wide and the workgroup has 4*XW waves;
+// wave (xw, wr) = (wave / 4, wave % 4) stores rows wr, wr+4, ... of the xw-th 256-sample column, so
+// with XW = 2 the two halves of a 2-KiB output row are written by sibling waves at the same time.
 template <int NB, int XW>
-__global__ __launch_bounds__(256 * XW + 64) void grid3d_sep_kernel(const SepArgs a)
+__global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
 {
     extern __shared__ float lds[];
     // per-band sample tables, triple buffered: slots 0..7 y samples, 8..15 z samples,
@@ -130,11 +126,9 @@ __global__ __launch_bounds__(256 * XW + 64) void grid3d_sep_kernel(const SepArgs
     int bz = (item - bx * nyz) / a.nby;
     int by = item - bx * nyz - bz * a.nby;
 
-    // sample tables of a brick (loader wave: one (band, slot) pair per lane and pass)
     auto fill_tables = [&](int buf, int tbx, int tby, int tbz) {
-        for (int e = lane; e < NB * 32; e += 64) {
-            const int b = e >> 5, slot = e & 31;
-            if (slot >= 18) continue;
+        const int b = tid >> 5, slot = tid & 31;
+        if (b < NB && slot < 18) {
             int idx;
             bool is_const = false;
             if (slot < 8) idx = min(tby * kBrickY + slot, g.ny - 1);
@@ -174,38 +168,43 @@ __global__ __launch_bounds__(256 * XW + 64) void grid3d_sep_kernel(const SepArgs
         return o;
     };
 
-    // Loader wave: box rows are (k, j) pairs, r = k*ey + j; the row part of every address is scalar,
-    // a lane contributes only its column (256-B coalesced reads).  kChunk rows are kept in flight.
+    // Box rows are (k, j) pairs, r = k*ey + j; wave w takes rows w, w+4, ...: the row part of every
+    // address is scalar, a lane contributes only its column.  Columns 0..63 in `pf`, the (at most
+    // 27) columns from 64 on in `pfx`.
+    constexpr int kRowsPerWave = (kBoxY * kBoxZ + kWaves - 1) / kWaves;
     constexpr int kColGroups = (kBrickX / 3 + 8 + 63) / 64; // 64-column groups a box can span (step <= 1/3)
-    constexpr int kChunk = 8;
-    auto load_box = [&](int tb, int b, int box_buf) {
-        const Box o = box_of(tb, b);
+    float pf[kRowsPerWave][kColGroups];
+    auto issue_box = [&](int buf, int b) {
+        const Box o = box_of(buf, b);
+        int k = 0, j = wave;
+#pragma unroll
+        for (int t = 0; t < kRowsPerWave; ++t) {
+            while (j >= o.ey) { j -= o.ey; ++k; }
+            const bool row_on = wave + kWaves * t < o.nrows;
+            const float *row = a.coef + (((o.kz0 + k) & a.nmask) * a.n + ((o.jy0 + j) & a.nmask)) * a.n;
+#pragma unroll
+            for (int c = 0; c < kColGroups; ++c) {
+                pf[t][c] = 0.0f;
+                if (row_on && 64 * c < o.ex && lane + 64 * c < o.ex)
+                    pf[t][c] = row[(o.ix0 + 64 * c + lane) & a.nmask];
+            }
+            j += kWaves;
+        }
+    };
+    auto commit_box = [&](int buf, int b, int box_buf) {
+        const Box o = box_of(buf, b);
         float *col = lds + a.band[b].box_off + box_buf * a.box_buf_stride + lane * kColStride;
-        int k = 0, j = 0;
-        for (int r0 = 0; r0 < o.nrows; r0 += kChunk) {
-            float v[kChunk][kColGroups];
-            int kk = k, jj = j;
+        int k = 0, j = wave;
 #pragma unroll
-            for (int t = 0; t < kChunk; ++t) {
-                const float *row = a.coef + (((o.kz0 + kk) & a.nmask) * a.n + ((o.jy0 + jj) & a.nmask)) * a.n;
+        for (int t = 0; t < kRowsPerWave; ++t) {
+            while (j >= o.ey) { j -= o.ey; ++k; }
+            if (wave + kWaves * t < o.nrows) {
+                const int at = k * kBoxY + j;
 #pragma unroll
-                for (int c = 0; c < kColGroups; ++c) {
-                    v[t][c] = 0.0f;
-                    if (r0 + t < o.nrows && 64 * c < o.ex && lane + 64 * c < o.ex)
-                        v[t][c] = row[(o.ix0 + 64 * c + lane) & a.nmask];
-                }
-                if (++jj == o.ey) { jj = 0; ++kk; }
+                for (int c = 0; c < kColGroups; ++c)
+                    if (64 * c < o.ex && lane + 64 * c < o.ex) col[64 * c * kColStride + at] = pf[t][c];
             }
-#pragma unroll
-            for (int t = 0; t < kChunk; ++t) {
-                if (r0 + t < o.nrows) {
-                    const int at = k * kBoxY + j;
-#pragma unroll
-                    for (int c = 0; c < kColGroups; ++c)
-                        if (64 * c < o.ex && lane + 64 * c < o.ex) col[64 * c * kColStride + at] = v[t][c];
-                }
-                if (++j == o.ey) { j = 0; ++k; }
-            }
+            j += kWaves;
         }
     };
 
@@ -354,28 +353,29 @@ __global__ __launch_bounds__(256 * XW + 64) void grid3d_sep_kernel(const SepArgs
     };
 
     // ---- pipeline ---------------------------------------------------------------------------------
-    // Tables are triple buffered (brick t in slot t%3), R and the coefficient boxes double buffered;
-    // a brick costs ONE workgroup barrier:
-    //     compute waves:  [phase 1(t): box[t&1] -> R[t&1]]                 barrier  [phase C(t): R[t&1] -> stores]
-    //     loader wave:    [box(t+1) -> box[(t+1)&1]] [tables(t+2)]         barrier
-    // Compute waves that finish their stores early run ahead into phase 1 of the next brick.
-    const bool loader = wave == kWaves;
+    // Tables are triple buffered (brick t in slot t%3).
+    // NB == 1: R and the coefficient box are double buffered and a brick costs ONE barrier:
+    //     [issue loads of box(t+1)] [phase 1(t) -> R[t&1]] [commit box(t+1)] [tables(t+2)]
+    //     barrier
+    //     [phase C(t): R[t&1] -> stores]
+    //   The loads of brick t+1 are in flight during phase 1 and retired BEFORE brick t's stores are
+    //   issued, so the vmcnt wait that retires them only has brick t-1's stores ahead of it; waves
+    //   that finish their stores early run ahead into phase 1 of the next brick.
+    // NB > 1: single R and box (LDS and registers are the scarce resources there), boxes loaded
+    //   band by band at the top of the brick: two barriers per brick.
     int tb = 0, par = 0;
+    fill_tables(0, bx, by, bz);
     int n1x = bx, n1y = by, n1z = bz; // brick t+1
     next_brick(n1x, n1y, n1z);
-    if (loader) {
-        fill_tables(0, bx, by, bz);
-        if (item + 1 < item_end) fill_tables(1, n1x, n1y, n1z);
-    }
+    if (item + 1 < item_end) fill_tables(1, n1x, n1y, n1z);
     __syncthreads();
-    int weights_bx = bx;
-    if (loader) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b) load_box(0, b, 0);
-    } else {
-        x_weights(0);
+    if (NB == 1) {
+        issue_box(0, 0);
+        commit_box(0, 0, 0);
     }
-    __syncthreads(); // box[0] complete
+    x_weights(0);
+    int weights_bx = bx;
+    if (NB == 1) __syncthreads();
 
     for (;;) {
         const bool has_next = item + 1 < item_end;
@@ -383,17 +383,24 @@ __global__ __launch_bounds__(256 * XW + 64) void grid3d_sep_kernel(const SepArgs
         int n2x = n1x, n2y = n1y, n2z = n1z; // brick t+2
         next_brick(n2x, n2y, n2z);
 
-        if (loader) {
-            if (has_next) {
-#pragma unroll
-                for (int b = 0; b < NB; ++b) load_box(tb1, b, par ^ 1);
-            }
+        if (NB == 1) {
+            if (has_next) issue_box(tb1, 0);
+            phase1(tb, par, par);
+            if (has_next) commit_box(tb1, 0, par ^ 1);
             if (item + 2 < item_end) fill_tables(tb2, n2x, n2y, n2z);
             __syncthreads();
-        } else {
-            phase1(tb, par, par);
-            __syncthreads();
             phaseC(par);
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                issue_box(tb, b);
+                commit_box(tb, b, 0);
+            }
+            __syncthreads(); // boxes complete; previous phase C done (R free)
+            phase1(tb, 0, 0);
+            if (item + 2 < item_end) fill_tables(tb2, n2x, n2y, n2z);
+            __syncthreads(); // R complete; the boxes may be overwritten
+            phaseC(0);
         }
 
         if (!has_next) break;
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(256 * XW + 64) void grid3d_sep_kernel(const SepArgs
         n1x = n2x; n1y = n2y; n1z = n2z;
         tb = tb1;
         par ^= 1;
-        if (!loader && bx != weights_bx) { // tables of the new brick became visible at least one barrier ago
+        if (bx != weights_bx) { // tables of the new brick became visible at least one barrier ago
             x_weights(tb);
             weights_bx = bx;
         }
@@ -557,18 +564,18 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
         a->band[b].box_off = (int)box_total;
         box_total += (size_t)exs[b] * kColStride;
     }
-    // two copies of every box and of R (one-barrier pipeline with a loader wave)
-    const int copies = 2;
-    a->box_buf_stride = (int)box_total;
+    // single band: two copies of box and R (one-barrier pipeline); several bands: one copy each
+    const int copies = nbands == 1 ? 2 : 1;
+    a->box_buf_stride = nbands == 1 ? (int)box_total : 0;
     size_t off = copies * box_total; // boxes first, then the R rows
     for (int b = 0; b < nbands; ++b) {
         a->band[b].r_off = (int)(off + r_total);
         r_total += (size_t)rows * (exs[b] | 1) + 4;
     }
-    a->r_buf_stride = (int)r_total;
+    a->r_buf_stride = nbands == 1 ? (int)r_total : 0;
     off += copies * r_total;
     *lds_bytes = off * sizeof(float);
-    if (*lds_bytes > 150 * 1024) return false;
+    if (*lds_bytes > 120 * 1024) return false;
     a->bz_log2 = __builtin_ctz(BZ);
     a->nbx = (g.nx + kBrickX - 1) / kBrickX;
     a->nby = (g.ny + kBrickY - 1) / kBrickY;
@@ -603,7 +610,7 @@ int persistent_grid(long long items, size_t lds_bytes, int xw)
 {
     const int cus = compute_units();
     int kmax = (int)((160 * 1024) / (lds_bytes + 2048));
-    const int wave_cap = 32 / (4 * xw + 1); // 32 waves per CU, 4*xw compute waves + 1 loader per workgroup
+    const int wave_cap = 8 / xw; // 32 waves per CU
     kmax = kmax > wave_cap ? wave_cap : (kmax < 1 ? 1 : kmax);
     int best_k = kmax;
     double best_eff = -1.0;
@@ -624,11 +631,11 @@ void launch_sep2(const SepArgs &a, size_t lds, hipStream_t s)
     static bool big_lds_enabled = false; // dynamic LDS beyond 64 KiB needs the opt-in once per kernel
     if (lds > 48 * 1024 && !big_lds_enabled) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&grid3d_sep_kernel<NB, XW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         big_lds_enabled = true;
     }
     hipLaunchKernelGGL((grid3d_sep_kernel<NB, XW>), dim3(persistent_grid(items, lds, XW)),
-                       dim3(256 * XW + 64), lds, s, a);
+                       dim3(256 * XW), lds, s, a);
 }
 
 template <int NB>
