@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=512, help="lattice size per axis per GPU")
+    ap.add_argument("--lattice", dest="n", type=int, default=512, help="lattice size per axis per GPU")
     ap.add_argument("--workload", default="wavelet3d",
                     choices=["wavelet3d", "wavelet3d_exact", "multiband5", "turb7", "perlin",
                              "texture_points"])
@@ -101,11 +101,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
-    torch.cuda.set_device(local)
+    # one rank per GPU; WN_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the
+    # multi-rank path on a single-GPU box (the driver's runs use the default: nccl = RCCL)
+    backend = os.environ.get("WN_BENCH_BACKEND", "nccl")
+    device_index = local % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     wn = importlib.import_module("wavelet-noise-in-ray-tracing_amd")
     n = args.n
@@ -174,13 +181,13 @@ def main():
     dt = time.perf_counter() - t0
     ev_ms = timer.elapsed_ms()
     if dist is not None:
-        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
 
     gather = None
     if args.gather and dist is not None:
-        slab = out.view(n, n, n)
+        slab = out.view(n, n, n) if backend == "nccl" else out.view(n, n, n).cpu()
         torch.cuda.synchronize(); barrier()
         g0 = time.perf_counter()
         wn.gather_volume(slab, n * world, dst=0)
@@ -202,7 +209,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_us": launch_s * 1e6, "traffic": pmc_traffic()},
+                         "avg_launch_us": launch_s * 1e6,
+                         "traffic": pmc_traffic() if (args.workload == "wavelet3d" and n == 512) else None},
         }
         if gather:
             line["gather"] = gather

@@ -136,9 +136,14 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
                 idx = g.z0 + min(tbz * BZ + min(slot - 8, BZ - 1), g.nz - 1);
                 is_const = g.z_const_mode != 0;
             } else idx = (slot == 16) ? tbx * kBrickX : min(tbx * kBrickX + kBrickX - 1, g.nx - 1);
+            // band scale by selects: a per-lane index into the kernel arguments would become a
+            // vector-memory load, and its vmcnt(0) wait would queue behind this wave's stores
+            float oscale = a.band[0].oscale;
+#pragma unroll
+            for (int bb = 1; bb < NB; ++bb) oscale = (b == bb) ? a.band[bb].oscale : oscale;
             const float c = is_const ? g.z_const
-                                     : lattice_coord_fast(idx, den, a.inv_den, g.base_range,
-                                                          a.band[b].oscale, g.post_scale);
+                                     : lattice_coord_fast(idx, den, a.inv_den, g.base_range, oscale,
+                                                          g.post_scale);
             int m;
             float w0, w1, w2;
             wn::bspline(c, m, w0, w1, w2);
