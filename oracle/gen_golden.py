@@ -36,6 +36,54 @@ def sha256(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()
 
 
+def decode_png_rgb(path):
+    """Minimal 8-bit RGB, non-interlaced PNG decoder (the reference's stb_image_write output)."""
+    import struct
+    import zlib
+    d = open(path, "rb").read()
+    assert d[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(d):
+        ln = struct.unpack(">I", d[pos:pos + 4])[0]
+        typ, body = d[pos + 4:pos + 8], d[pos + 8:pos + 8 + ln]
+        if typ == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
+            assert depth == 8 and ctype == 2
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + ln
+    rawb = zlib.decompress(idat)
+    bpp, stride = 3, w * 3
+    img = np.zeros((h, stride), np.uint8)
+    prev = np.zeros(stride, np.int64)
+    p = 0
+    for y in range(h):
+        f = rawb[p]
+        line = np.frombuffer(rawb[p + 1:p + 1 + stride], np.uint8).astype(np.int64)
+        p += 1 + stride
+        if f == 0:
+            cur = line
+        elif f == 2:
+            cur = (line + prev) & 255
+        else:
+            cur = np.zeros(stride, np.int64)
+            for i in range(stride):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                if f == 1:
+                    pr = a
+                elif f == 3:
+                    pr = (a + b) >> 1
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (line[i] + pr) & 255
+        img[y] = cur
+        prev = cur
+    return img.reshape(h, w, 3)
+
+
 def special_points():
     """Coordinates the B-spline / floor logic is sensitive to: integers, half-integers,
     negatives, tile-period multiples, the scene extremes (lattice +-320)."""
@@ -65,8 +113,23 @@ def main():
     for p in sorted(glob.glob(os.path.join(REF, "experient/result_raw/*.raw"))):
         shutil.copyfile(p, os.path.join(GOLD, "result_raw", os.path.basename(p)))
         art["raw"][os.path.basename(p)] = sha256(p)
+    art["png_rgb_sha256"] = {}
     for p in sorted(glob.glob(os.path.join(REF, "result_raytracing/*.png"))):
         art["png"][os.path.basename(p)] = sha256(p)
+        rgb = decode_png_rgb(p)  # pixel content of the committed render (the PNG container is stb's)
+        art["png_rgb_sha256"][os.path.basename(p)] = {"shape": list(rgb.shape),
+                                                      "sha256": hashlib.sha256(rgb.tobytes()).hexdigest()}
+    # hit-point stream of the reference's render loop (oracle/_ref/raytrace_record: the reference's
+    # unmodified main.cpp with oracle/ref_record_texture.h): count and FNV-1a64 of every p passed to
+    # tex->value(), 1000x500x100 spp; identical for both noise types (noise never steers the paths)
+    import subprocess
+    import tempfile
+    rec = os.path.join(ROOT, "oracle", "_ref", "raytrace_record")
+    if os.path.exists(rec):
+        with tempfile.TemporaryDirectory() as td:
+            proc = subprocess.run([rec], input="1\n4\n", cwd=td, capture_output=True, text=True)
+        line = [ln for ln in proc.stderr.splitlines() if ln.startswith("WN_RECORD")][-1]
+        art["render_hit_stream"] = dict(kv.split("=") for kv in line.split()[1:])
     stats = {}
     for p in sorted(glob.glob(os.path.join(REF, "threejs/result_json/*.json"))):
         j = json.load(open(p))
