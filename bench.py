@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--lattice", dest="n", type=int, default=512, help="lattice size per axis per GPU")
+    ap.add_argument("--planes", type=int, default=0,
+                    help="z-planes per GPU (default: --lattice); --lattice 2048 --planes 256 is one "
+                         "GPU's slab of BASELINE configs[4] (2048^3 over 8 GPUs)")
     ap.add_argument("--workload", default="wavelet3d",
                     choices=["wavelet3d", "wavelet3d_exact", "multiband5", "turb7", "perlin",
                              "texture_points"])
@@ -67,7 +70,7 @@ def cpu_baseline(n, budget_s, gpu_slab):
         def run(z0, z1, out):
             oracle.lib().wno_grid_wavelet3d_volume(tile, tile.size, n, n, n, z0, z1, OCTAVE, out)
     buf = np.empty(planes_per_chunk * n * n, np.float32)
-    while t_used < budget_s and done + planes_per_chunk <= n:
+    while t_used < budget_s and done + planes_per_chunk <= gpu_slab.shape[0]:
         t0 = time.perf_counter()
         run(done, done + planes_per_chunk, buf)
         t_used += time.perf_counter() - t0
@@ -116,8 +119,9 @@ def main():
 
     wn = importlib.import_module("wavelet-noise-in-ray-tracing_amd")
     n = args.n
-    z0, z1 = rank * n, (rank + 1) * n  # this rank's slab of the n x n x (n*world) lattice
-    samples_per_rank = n * n * n
+    planes = args.planes or n
+    z0, z1 = rank * planes, (rank + 1) * planes  # this rank's slab of the n x n x (planes*world) lattice
+    samples_per_rank = n * n * planes
     out = torch.empty(samples_per_rank, dtype=torch.float32, device="cuda")
 
     alg_bytes = 4 * samples_per_rank + 4 * TILE ** 3  # one fp32 store/sample + tile once
@@ -132,7 +136,8 @@ def main():
             exact = args.workload == "wavelet3d_exact"
             step = lambda: wn.wavelet_volume(noise, n, n, n, z0, z1, OCTAVE, exact=exact, out=out)  # noqa: E731
             kernel = "grid3d_direct_kernel" if exact else "grid3d_sep_kernel<1>"
-            desc = f"{n}^3 dense 3D WNoise grid, tile={TILE}, octave={OCTAVE} (configs[1])"
+            desc = (f"{n}^3 dense 3D WNoise grid, tile={TILE}, octave={OCTAVE} (configs[1])" if planes == n else
+                    f"{n}x{n}x{planes} z-slab per GPU of a {n}^2 x {planes}*N lattice, tile={TILE}, octave={OCTAVE} (configs[4] shard)")
     elif args.workload in ("turb7", "perlin"):
         per = wn.perlin(SEED)
         dtype = "f64"
@@ -187,10 +192,10 @@ def main():
 
     gather = None
     if args.gather and dist is not None:
-        slab = out.view(n, n, n) if backend == "nccl" else out.view(n, n, n).cpu()
+        slab = out.view(planes, n, n) if backend == "nccl" else out.view(planes, n, n).cpu()
         torch.cuda.synchronize(); barrier()
         g0 = time.perf_counter()
-        wn.gather_volume(slab, n * world, dst=0)
+        wn.gather_volume(slab, planes * world, dst=0)
         torch.cuda.synchronize(); barrier()
         gs = time.perf_counter() - g0
         gather = {"ms": gs * 1e3, "GBps_into_root": 4.0 * samples_per_rank * (world - 1) / gs / 1e9}
@@ -203,19 +208,19 @@ def main():
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": desc, "lattice_per_gpu": [n, n, n], "tile": TILE, "seed": SEED,
+            "config": {"workload": desc, "lattice_per_gpu": [n, n, planes], "tile": TILE, "seed": SEED,
                        "octave": OCTAVE, "sharding": "z-slabs, no data-path collective",
                        "device": wn.device_info()["name"]},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": launch_s * 1e6,
-                         "traffic": pmc_traffic() if (args.workload == "wavelet3d" and n == 512) else None},
+                         "traffic": pmc_traffic() if (args.workload == "wavelet3d" and n == 512 and planes == 512) else None},
         }
         if gather:
             line["gather"] = gather
         if world == 1 and not args.no_cpu_baseline and args.workload == "wavelet3d":
-            line["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds, out.view(n, n, n))
+            line["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds, out.view(planes, n, n))
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

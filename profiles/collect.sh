@@ -19,5 +19,7 @@ done
 for wl in multiband5 turb7 perlin texture_points wavelet3d_exact; do
   python3 $ROOT/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_$wl.json" 2> "$OUT/bench_$wl.err" || echo "bench $wl failed"
 done
+python3 $ROOT/bench.py --lattice 1024 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_wavelet3d_1024.json" 2> /dev/null || echo "bench 1024 failed"
+python3 $ROOT/bench.py --lattice 2048 --planes 256 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_wavelet3d_2048x2048x256.json" 2> /dev/null || echo "bench shard failed"
 python3 $ROOT/bench.py --steps 50 --warmup 5 > "$OUT/bench_wavelet3d.json" 2> "$OUT/bench_wavelet3d.err" || echo "bench failed"
 echo collected
