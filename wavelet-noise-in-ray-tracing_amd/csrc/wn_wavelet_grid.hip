@@ -42,7 +42,7 @@ constexpr int kColStride = kBoxY * kBoxZ + 1; // LDS floats per box column (odd:
 
 struct BandArgs {
     float oscale; // octave_scale of this band
-    float weight; // w[b]
+    float factor; // everything that scales this band's contribution: w[b] * out_scale / out_div
     int box_off;  // float offset of this band's coefficient box in dynamic LDS
     int r_off;    // float offset of this band's collapsed rows
 };
@@ -57,7 +57,6 @@ struct SepArgs {
     int r_buf_stride;   // ... and of the R region (single band only, else 0)
     int nbx, nby, nbz;
     int nbands;
-    float out_div;
     float inv_den; // 1/den when den is a power of two (exact), else 0
     int vec4_ok;
     int xw; // wave columns per brick (1 or 2)
@@ -282,7 +281,7 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
 #pragma unroll
                         for (int j = 0; j < 3; ++j)
                             if (k | j) acc = __builtin_fmaf(w9[k][j], c[k * kBoxY + j], acc);
-                    *R = (NB == 1) ? acc * g.out_scale : acc;
+                    *R = acc * a.band[b].factor;
                 }
             }
         }
@@ -305,17 +304,14 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
                 Rl[b] += 4 * rs_[b];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float t = ww[b][q][0] * v0;
+                    // the band factor (weight, 1/sqrt(variance), out_scale) is already in R: one FMA
+                    // chain over taps and bands, no per-sample scaling or division
+                    float t = (b == 0) ? ww[b][q][0] * v0 : __builtin_fmaf(ww[b][q][0], v0, acc[q]);
                     t = __builtin_fmaf(ww[b][q][1], v1, t);
                     t = __builtin_fmaf(ww[b][q][2], v2, t);
                     t = __builtin_fmaf(ww[b][q][3], v3, t);
-                    if (NB == 1) acc[q] = t;
-                    else acc[q] = __builtin_fmaf(a.band[b].weight, t, acc[q]);
+                    acc[q] = t;
                 }
-            }
-            if (NB > 1) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = (acc[q] / a.out_div) * g.out_scale;
             }
         };
         // A wave owns rows wr, wr+4, ...: per z plane the y rows (wr) and (wr + 4).
@@ -539,7 +535,7 @@ inline int ceil_pow2(int v)
 
 // Plan the separable kernel; returns false when the lattice is outside its regime.
 bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *oscale,
-              const float *weights, SepArgs *a, size_t *lds_bytes)
+              const float *weights, float out_div, SepArgs *a, size_t *lds_bytes)
 {
     // two wave columns (512-sample bricks: whole 2-KiB rows written together) when the lattice is wide
     const int xw = g.nx > 256 ? 2 : 1;
@@ -565,7 +561,7 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
         exs[b] = extent(kBrickX) + 1;
         if (extent(kBrickY) > kBoxY || (!g.z_const_mode && extent(BZ) > kBoxZ)) return false;
         a->band[b].oscale = oscale[b];
-        a->band[b].weight = weights ? weights[b] : 1.0f;
+        a->band[b].factor = (float)((double)(weights ? weights[b] : 1.0f) * (double)g.out_scale / (double)out_div);
         a->band[b].box_off = (int)box_total;
         box_total += (size_t)exs[b] * kColStride;
     }
@@ -690,9 +686,8 @@ int wn_eval3d_grid(const wn_tile *tile, const wn_grid *grid, float *out_dev, voi
         SepArgs a{};
         size_t lds = 0;
         const float os = g.octave_scale;
-        if (plan_sep(tile, g, 1, &os, nullptr, &a, &lds)) {
+        if (plan_sep(tile, g, 1, &os, nullptr, 1.0f, &a, &lds)) {
             a.out = out_dev;
-            a.out_div = 1.0f;
             a.vec4_ok = (g.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
             return run_sep(a, lds, as_stream(stream));
         }
@@ -750,17 +745,10 @@ int wn_multiband3d_grid(const wn_tile *tile, const wn_grid *grid, float s, int f
         size_t lds = 0;
         GridArgs gb = g;
         gb.post_scale = 2.0f;
-        if (plan_sep(tile, gb, active, oscale, wts, &a, &lds)) {
+        if (plan_sep(tile, gb, active, oscale, wts, out_div, &a, &lds)) {
             a.out = out_dev;
-            a.out_div = out_div;
             a.vec4_ok = (g.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
-            if (active == 1) {
-                // single active band: the NB==1 instantiation ignores weight/out_div; fold them
-                // into out_scale only when that is exact, otherwise use the exact kernel.
-                if (wts[0] == 1.0f && out_div == 1.0f) return run_sep(a, lds, as_stream(stream));
-            } else {
-                return run_sep(a, lds, as_stream(stream));
-            }
+            return run_sep(a, lds, as_stream(stream));
         }
     }
     DirectArgs d{};
