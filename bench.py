@@ -131,11 +131,11 @@ def main():
         noise.generateNoiseTile3D()  # every rank regenerates the tile from the seed
         if args.workload == "multiband5":
             step = lambda: wn.multiband_volume(noise, n, n, n, z0, z1, -16.0, 0, 5, out=out)  # noqa: E731
-            kernel, desc = "grid3d_sep_kernel<5>", f"{n}^3 WMultibandNoise 5 bands (configs[2])"
+            kernel, desc = "grid3d_sep_kernel<NB=5>", f"{n}^3 WMultibandNoise 5 bands (configs[2])"
         else:
             exact = args.workload == "wavelet3d_exact"
             step = lambda: wn.wavelet_volume(noise, n, n, n, z0, z1, OCTAVE, exact=exact, out=out)  # noqa: E731
-            kernel = "grid3d_direct_kernel" if exact else "grid3d_sep_kernel<1>"
+            kernel = "grid3d_direct_kernel" if exact else "grid3d_sep_kernel<NB=1>"
             desc = (f"{n}^3 dense 3D WNoise grid, tile={TILE}, octave={OCTAVE} (configs[1])" if planes == n else
                     f"{n}x{n}x{planes} z-slab per GPU of a {n}^2 x {planes}*N lattice, tile={TILE}, octave={OCTAVE} (configs[4] shard)")
     elif args.workload in ("turb7", "perlin"):

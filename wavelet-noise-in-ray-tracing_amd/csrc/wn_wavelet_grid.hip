@@ -629,11 +629,13 @@ template <int NB, int XW>
 void launch_sep2(const SepArgs &a, size_t lds, hipStream_t s)
 {
     const long long items = (long long)a.nbx * a.nby * a.nbz;
-    static bool big_lds_enabled = false; // dynamic LDS beyond 64 KiB needs the opt-in once per kernel
-    if (lds > 48 * 1024 && !big_lds_enabled) {
+    static int big_lds_device = -1; // dynamic LDS beyond 64 KiB needs a per-device opt-in for this kernel
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (lds > 48 * 1024 && big_lds_device != dev) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&grid3d_sep_kernel<NB, XW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        big_lds_enabled = true;
+        big_lds_device = dev;
     }
     hipLaunchKernelGGL((grid3d_sep_kernel<NB, XW>), dim3(persistent_grid(items, lds, XW)),
                        dim3(256 * XW), lds, s, a);
