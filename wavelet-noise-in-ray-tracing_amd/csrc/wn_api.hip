@@ -341,6 +341,12 @@ int wn_tile_create(int n, int dims, const float *coeffs_host, wn_tile **out)
             *out = nullptr;
             return hip_fail(e, "hipMemcpy(tile)");
         }
+        rc = tile_build_padded(*out, nullptr);
+        if (rc) {
+            wn_tile_destroy(*out);
+            *out = nullptr;
+            return rc;
+        }
     }
     return WN_OK;
 }
@@ -368,6 +374,7 @@ int wn_tile_generate_from_field(int n, int dims, const float *field_host, wn_til
     hipError_t se = hipStreamSynchronize(nullptr);
     (void)hipFree(field_dev);
     if (rc == WN_OK && se != hipSuccess) rc = hip_fail(se, "tile generation");
+    if (rc == WN_OK) rc = tile_build_padded(t, nullptr);
     if (rc) {
         wn_tile_destroy(t);
         *out = nullptr;
@@ -409,6 +416,7 @@ void wn_tile_destroy(wn_tile *t)
     WN_ENTRY();
     if (!t) return;
     if (t->dev) (void)hipFree(t->dev);
+    if (t->dev_padded) (void)hipFree(t->dev_padded);
     delete t;
 }
 

@@ -34,6 +34,10 @@ __device__ __forceinline__ float eval2d_exact(const float *coef, int n, int nmas
 }
 
 // WaveletNoise::evaluate3D, WaveletNoise.cpp:185-215 (f2 outer, f0 inner; weight=(w0*w1)*w2).
+// PADDED: `coef` is wn_tile::dev_padded (row stride n+2 with two wrap-around columns), so the
+// three x taps of every (y,z) row are adjacent and fetched with one 12-byte load; the values, the
+// arithmetic and its order are those of the linear layout.
+template <bool PADDED = false>
 __device__ __forceinline__ float eval3d_exact(const float *coef, int n, int nmask, float px,
                                               float py, float pz)
 {
@@ -43,23 +47,32 @@ __device__ __forceinline__ float eval3d_exact(const float *coef, int n, int nmas
     bspline(px, mx, wx[0], wx[1], wx[2]);
     bspline(py, my, wy[0], wy[1], wy[2]);
     bspline(pz, mz, wz[0], wz[1], wz[2]);
+    const int stride = PADDED ? n + 2 : n;
     int cx[3], cy[3], cz[3];
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         cx[f] = dmod(mx + f - 1, n, nmask);
-        cy[f] = dmod(my + f - 1, n, nmask) * n;
-        cz[f] = dmod(mz + f - 1, n, nmask) * n * n;
+        cy[f] = dmod(my + f - 1, n, nmask) * stride;
+        cz[f] = dmod(mz + f - 1, n, nmask) * stride * n;
     }
     float result = 0.0f;
 #pragma unroll
     for (int fz = 0; fz < 3; ++fz)
 #pragma unroll
-        for (int fy = 0; fy < 3; ++fy)
+        for (int fy = 0; fy < 3; ++fy) {
+            float c[3];
+            if (PADDED) {
+                __builtin_memcpy(c, coef + cx[0] + cy[fy] + cz[fz], sizeof(c)); // global_load_dwordx3
+            } else {
+#pragma unroll
+                for (int fx = 0; fx < 3; ++fx) c[fx] = coef[cx[fx] + cy[fy] + cz[fz]];
+            }
 #pragma unroll
             for (int fx = 0; fx < 3; ++fx) {
                 const float weight = wx[fx] * wy[fy] * wz[fz];
-                result += weight * coef[cx[fx] + cy[fy] + cz[fz]];
+                result += weight * c[fx];
             }
+        }
     return result;
 }
 

@@ -7,6 +7,8 @@
 // lines through LDS; the last pass subtracts from the Gaussian field in place of a 4th kernel.
 #include "wn_internal.hpp"
 
+#include <algorithm>
+
 namespace {
 
 // Appendix-1 filter as the reference holds it (WaveletNoise.cpp:11-18).
@@ -95,9 +97,39 @@ int run_pass(const PassArgs &args, int count_b, hipStream_t stream)
     return WN_OK;
 }
 
+// rows with two wrap-around columns appended: dst[(z*n + y)*(n+2) + x] = src[(z*n + y)*n + (x mod n)]
+__global__ __launch_bounds__(256) void padded_copy_kernel(const float *src, float *dst, int n)
+{
+    const int stride = n + 2;
+    const size_t total = (size_t)stride * n * n;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(e % stride);
+        const size_t row = e / stride;
+        dst[e] = src[row * n + (x >= n ? x - n : x)];
+    }
+}
+
 } // namespace
 
 namespace wn {
+
+int tile_build_padded(wn_tile *t, hipStream_t stream)
+{
+    if (t->dims != 3 || t->n == 0) return WN_OK;
+    const size_t total = (size_t)(t->n + 2) * t->n * t->n;
+    if (!t->dev_padded) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->dev_padded), total * sizeof(float));
+        if (e != hipSuccess) {
+            hip_fail(e, "hipMalloc(padded tile)");
+            return WN_ERR_ALLOC;
+        }
+    }
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(padded_copy_kernel, dim3(blocks), dim3(256), 0, stream, t->dev, t->dev_padded, t->n);
+    WN_LAUNCH_CHECK("padded_copy_kernel");
+    WN_HIP(hipStreamSynchronize(stream));
+    return WN_OK;
+}
 
 int tilegen_filter(wn_tile *t, const float *field_dev, hipStream_t stream)
 {

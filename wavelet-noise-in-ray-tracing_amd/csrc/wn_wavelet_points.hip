@@ -30,12 +30,13 @@ struct PointsArgs {
     int apply_div;
 };
 
+template <bool PADDED>
 __global__ __launch_bounds__(256) void eval3d_points_kernel(const PointsArgs a)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.count;
          i += (size_t)gridDim.x * blockDim.x) {
         const float *p = a.pts + 3 * i;
-        a.out[i] = wn::eval3d_exact(a.coef, a.n, a.nmask, p[0], p[1], p[2]);
+        a.out[i] = wn::eval3d_exact<PADDED>(a.coef, a.n, a.nmask, p[0], p[1], p[2]);
     }
 }
 
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void eval3d_projected_points_kernel(const Poin
 }
 
 // WMultibandNoise (paper Appendix 2, normal == NULL) per point.
+template <bool PADDED>
 __global__ __launch_bounds__(256) void multiband3d_points_kernel(const PointsArgs a)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.count;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void multiband3d_points_kernel(const PointsArg
         float v = 0.0f;
         for (int b = 0; b < a.nbands; ++b) {
             const float s = a.band_scale[b];
-            v += a.band_w[b] * wn::eval3d_exact(a.coef, a.n, a.nmask, 2.0f * p[0] * s,
+            v += a.band_w[b] * wn::eval3d_exact<PADDED>(a.coef, a.n, a.nmask, 2.0f * p[0] * s,
                                                 2.0f * p[1] * s, 2.0f * p[2] * s);
         }
         if (a.apply_div) v /= a.out_div;
@@ -90,6 +92,7 @@ struct TexArgs {
     int points_per_wave;
 };
 
+template <bool PADDED>
 __device__ __forceinline__ float wavelet_texture_value(const TexArgs &a, float px, float py,
                                                        float pz)
 {
@@ -100,7 +103,7 @@ __device__ __forceinline__ float wavelet_texture_value(const TexArgs &a, float p
         pos[0] *= a.octave_mul;
         pos[1] *= a.octave_mul;
         pos[2] *= a.octave_mul;
-        v = (double)wn::eval3d_exact(a.coef, a.n, a.nmask, pos[0], pos[1], pos[2]);
+        v = (double)wn::eval3d_exact<PADDED>(a.coef, a.n, a.nmask, pos[0], pos[1], pos[2]);
         v *= (double)a.inv_stddev;
     } else if (a.mode == 2) {
         float pos[2] = {(float)((double)px * a.scale), (float)((double)py * a.scale)};
@@ -116,7 +119,7 @@ __device__ __forceinline__ float wavelet_texture_value(const TexArgs &a, float p
     return (float)(0.5 * (1.0 + c));                              // texture.h:104-106
 }
 
-template <bool MASKED>
+template <bool MASKED, bool PADDED>
 __global__ __launch_bounds__(256) void wavelet_texture_kernel(const TexArgs a)
 {
     // per-wave compaction queue: up to 63 carried + 64 new hits
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void wavelet_texture_kernel(const TexArgs a)
     if (!MASKED) {
         for (size_t i = begin + lane; i < end; i += 64) {
             const float *p = a.pts + 3 * i;
-            a.grey[i] = wavelet_texture_value(a, p[0], p[1], p[2]);
+            a.grey[i] = wavelet_texture_value<PADDED>(a, p[0], p[1], p[2]);
         }
         return;
     }
@@ -172,14 +175,14 @@ __global__ __launch_bounds__(256) void wavelet_texture_kernel(const TexArgs a)
                 q_i[wave][lane] = ci;
             }
             queued = rest;
-            a.grey[begin + idx] = wavelet_texture_value(a, x, y, z);
+            a.grey[begin + idx] = wavelet_texture_value<PADDED>(a, x, y, z);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
     if (lane < queued) { // tail batch
         const unsigned idx = q_i[wave][lane];
         a.grey[begin + idx] =
-            wavelet_texture_value(a, q_x[wave][lane], q_y[wave][lane], q_z[wave][lane]);
+            wavelet_texture_value<PADDED>(a, q_x[wave][lane], q_y[wave][lane], q_z[wave][lane]);
     }
 }
 
@@ -198,7 +201,7 @@ int fill_common(const wn_tile *tile, int dims, const void *pts, size_t n, const 
     if (tile->count && tile->dims != dims)
         return wn::fail(WN_ERR_INVALID, "tile is %d-D, this entry point needs %d-D", tile->dims, dims);
     if (n && (!pts || !out)) return wn::fail(WN_ERR_INVALID, "points/out pointer is NULL");
-    a->coef = tile->dev;
+    a->coef = (dims == 3 && tile->dev_padded) ? tile->dev_padded : tile->dev;
     a->n = tile->n;
     a->nmask = pow2_mask(tile->n);
     a->count = n;
@@ -222,7 +225,10 @@ int wn_eval3d_points(const wn_tile *tile, const float *xyz_dev, size_t n, float 
     if (rc || n == 0) return rc;
     a.pts = xyz_dev;
     a.out = out_dev;
-    hipLaunchKernelGGL(eval3d_points_kernel, dim3(point_blocks(n)), dim3(256), 0, as_stream(stream), a);
+    if (tile->dev_padded)
+        hipLaunchKernelGGL(eval3d_points_kernel<true>, dim3(point_blocks(n)), dim3(256), 0, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(eval3d_points_kernel<false>, dim3(point_blocks(n)), dim3(256), 0, as_stream(stream), a);
     WN_LAUNCH_CHECK("eval3d_points_kernel");
     return WN_OK;
 }
@@ -253,6 +259,7 @@ int wn_eval3d_projected_points(const wn_tile *tile, const float *xyz_dev, const 
     rc = fill_common(tile, 3, xyz_dev, n, out_dev, &a);
     if (rc || n == 0) return rc;
     if (!normals_dev) return fail(WN_ERR_INVALID, "normals_dev is NULL");
+    a.coef = tile->dev; // the projected evaluator indexes the linear layout
     a.pts = xyz_dev;
     a.normals = normals_dev;
     a.out = out_dev;
@@ -288,8 +295,12 @@ int wn_multiband3d_points(const wn_tile *tile, const float *xyz_dev, size_t n, f
     }
     a.apply_div = variance != 0.0f;
     a.out_div = a.apply_div ? sqrtf(variance * var_per_band) : 1.0f;
-    hipLaunchKernelGGL(multiband3d_points_kernel, dim3(point_blocks(n)), dim3(256), 0,
-                       as_stream(stream), a);
+    if (tile->dev_padded)
+        hipLaunchKernelGGL(multiband3d_points_kernel<true>, dim3(point_blocks(n)), dim3(256), 0,
+                           as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(multiband3d_points_kernel<false>, dim3(point_blocks(n)), dim3(256), 0,
+                           as_stream(stream), a);
     WN_LAUNCH_CHECK("multiband3d_points_kernel");
     return WN_OK;
 }
@@ -323,12 +334,16 @@ int wn_wavelet_texture_points(const wn_tile *tile, int use_3d, double scale, int
     const size_t waves = (n + a.points_per_wave - 1) / a.points_per_wave;
     const size_t blocks = (waves + 3) / 4;
     if (blocks > 0x7fffffffull) return fail(WN_ERR_INVALID, "too many points");
-    if (active_dev)
-        hipLaunchKernelGGL(wavelet_texture_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
-                           as_stream(stream), a);
-    else
-        hipLaunchKernelGGL(wavelet_texture_kernel<false>, dim3((unsigned)blocks), dim3(256), 0,
-                           as_stream(stream), a);
+    const bool padded = has_tile && use_3d && tile->dev_padded;
+    if (padded) a.coef = tile->dev_padded;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (active_dev) {
+        if (padded) hipLaunchKernelGGL((wavelet_texture_kernel<true, true>), grid, block, 0, as_stream(stream), a);
+        else hipLaunchKernelGGL((wavelet_texture_kernel<true, false>), grid, block, 0, as_stream(stream), a);
+    } else {
+        if (padded) hipLaunchKernelGGL((wavelet_texture_kernel<false, true>), grid, block, 0, as_stream(stream), a);
+        else hipLaunchKernelGGL((wavelet_texture_kernel<false, false>), grid, block, 0, as_stream(stream), a);
+    }
     WN_LAUNCH_CHECK("wavelet_texture_kernel");
     return WN_OK;
 }
