@@ -433,6 +433,7 @@ struct DirectArgs {
     int apply_div;
 };
 
+template <bool PADDED>
 __global__ __launch_bounds__(256) void grid3d_direct_kernel(const DirectArgs a)
 {
     const GridArgs &g = a.g;
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void grid3d_direct_kernel(const DirectArgs a)
             const float pz = g.z_const_mode ? g.z_const
                                             : wn::lattice_coord(g.z0 + z, den, g.base_range,
                                                                 g.octave_scale, g.post_scale);
-            v = wn::eval3d_exact(a.coef, a.n, a.nmask, px, py, pz);
+            v = wn::eval3d_exact<PADDED>(a.coef, a.n, a.nmask, px, py, pz);
         } else {
             const float px = wn::lattice_coord(x, den, g.base_range, g.octave_scale, g.post_scale);
             const float py = wn::lattice_coord(y, den, g.base_range, g.octave_scale, g.post_scale);
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256) void grid3d_direct_kernel(const DirectArgs a)
             v = 0.0f;
             for (int b = 0; b < a.nbands; ++b) {
                 const float s = a.band_scale[b];
-                v += a.band_w[b] * wn::eval3d_exact(a.coef, a.n, a.nmask, 2.0f * px * s,
+                v += a.band_w[b] * wn::eval3d_exact<PADDED>(a.coef, a.n, a.nmask, 2.0f * px * s,
                                                 2.0f * py * s, 2.0f * pz * s);
             }
             if (a.apply_div) v /= a.out_div;
@@ -701,8 +702,12 @@ int wn_eval3d_grid(const wn_tile *tile, const wn_grid *grid, float *out_dev, voi
     d.nmask = pow2_mask(tile->n);
     d.g = g;
     d.nbands = 0;
-    hipLaunchKernelGGL(grid3d_direct_kernel, dim3(grid_blocks(total)), dim3(256), 0,
-                       as_stream(stream), d);
+    if (tile->dev_padded) {
+        d.coef = tile->dev_padded;
+        hipLaunchKernelGGL(grid3d_direct_kernel<true>, dim3(grid_blocks(total)), dim3(256), 0, as_stream(stream), d);
+    } else {
+        hipLaunchKernelGGL(grid3d_direct_kernel<false>, dim3(grid_blocks(total)), dim3(256), 0, as_stream(stream), d);
+    }
     WN_LAUNCH_CHECK("grid3d_direct_kernel");
     return WN_OK;
 }
@@ -772,8 +777,12 @@ int wn_multiband3d_grid(const wn_tile *tile, const wn_grid *grid, float s, int f
         d.band_scale[0] = 1.0f;
         d.band_w[0] = 0.0f;
     }
-    hipLaunchKernelGGL(grid3d_direct_kernel, dim3(grid_blocks(total)), dim3(256), 0,
-                       as_stream(stream), d);
+    if (tile->dev_padded) {
+        d.coef = tile->dev_padded;
+        hipLaunchKernelGGL(grid3d_direct_kernel<true>, dim3(grid_blocks(total)), dim3(256), 0, as_stream(stream), d);
+    } else {
+        hipLaunchKernelGGL(grid3d_direct_kernel<false>, dim3(grid_blocks(total)), dim3(256), 0, as_stream(stream), d);
+    }
     WN_LAUNCH_CHECK("grid3d_direct_kernel(multiband)");
     return WN_OK;
 }
