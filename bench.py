@@ -40,7 +40,7 @@ def parse():
                          "GPU's slab of BASELINE configs[4] (2048^3 over 8 GPUs)")
     ap.add_argument("--workload", default="wavelet3d",
                     choices=["wavelet3d", "wavelet3d_exact", "multiband5", "turb7", "perlin",
-                             "texture_points"])
+                             "texture_points", "texture_points_perlin"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--gather", action="store_true",
@@ -159,12 +159,15 @@ def main():
         k = int(0.15 * m)
         d = torch.randn((k, 3), device="cuda", generator=g)
         pts[:k] = torch.tensor([1.0, 0.0, -1.75], device="cuda") + 0.5 * d / d.norm(dim=1, keepdim=True)
-        tex = wn.wavelet_texture(1.0, OCTAVE, True)
+        perlin_tex = args.workload == "texture_points_perlin"
+        tex = wn.noise_texture(1.0, OCTAVE) if perlin_tex else wn.wavelet_texture(1.0, OCTAVE, True)
         grey = torch.empty(m, dtype=torch.float32, device="cuda")
         step = lambda: tex.grey(pts, out=grey)  # noqa: E731
         samples_per_rank = m
         alg_bytes = 16 * m  # 12 B xyz in + 4 B out
-        kernel, desc = "wavelet_texture_kernel", f"{m} ray hit points, wavelet_texture octave {OCTAVE} (configs[3] stand-in)"
+        kernel = "noise_texture_kernel" if perlin_tex else "wavelet_texture_kernel"
+        desc = f"{m} ray hit points, {'noise_texture (Perlin)' if perlin_tex else 'wavelet_texture'} octave {OCTAVE} (configs[3] stand-in)"
+        dtype = "f64" if perlin_tex else "f32"
 
     def barrier():
         if dist is not None:

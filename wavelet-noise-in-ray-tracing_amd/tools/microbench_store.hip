@@ -77,6 +77,30 @@ __global__ __launch_bounds__(256 * XW) void fill_shape(float *out, int N, float 
     }
 }
 
+// cache-policy variants of the persistent brick fill: MODE 0 plain, 1 sc1 (write-through, line dropped
+// from L2), 2 sc0 sc1, 3 nt
+template <int MODE>
+__global__ __launch_bounds__(256) void fill_policy(float *out, int N, float v)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nbx = N / 256, nby = N / 8, nbz = N / 8, nyz = nby * nbz;
+    const long long T = (long long)nbx * nyz;
+    int item = (int)(T * blockIdx.x / gridDim.x);
+    const int end = (int)(T * (blockIdx.x + 1) / gridDim.x);
+    for (; item < end; ++item) {
+        const int bx = item / nyz, yz = item - bx * nyz, bz = yz / nby, by = yz - bz * nby;
+        for (int row = wave; row < 64; row += 4) {
+            const int y = by * 8 + (row & 7), z = bz * 8 + (row >> 3);
+            v4f x = v4f{v, v + row, v + 2, v + 3};
+            v4f *dst = reinterpret_cast<v4f *>(out + ((size_t)z * N + y) * N + bx * 256) + lane;
+            if (MODE == 0) *dst = x;
+            else if (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(x) : "memory");
+            else if (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(x) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(x) : "memory");
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void copy_linear(const float4 *in, float4 *out, size_t n4)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = in[i];
@@ -121,6 +145,10 @@ int main()
         snprintf(nm, 64, "fill_bricks_persistent k=%d nt", k);
         report(nm, time_it([&] { fill_bricks_persistent<true><<<256 * k, 256>>>(out, N, 1.f); }, 20), bytes);
     }
+    report("policy plain    k=2", time_it([&] { fill_policy<0><<<512, 256>>>(out, N, 1.f); }, 20), bytes);
+    report("policy sc1      k=2", time_it([&] { fill_policy<1><<<512, 256>>>(out, N, 1.f); }, 20), bytes);
+    report("policy sc0 sc1  k=2", time_it([&] { fill_policy<2><<<512, 256>>>(out, N, 1.f); }, 20), bytes);
+    report("policy nt       k=2", time_it([&] { fill_policy<3><<<512, 256>>>(out, N, 1.f); }, 20), bytes);
     report("shape 256x8x8   k=2", time_it([&] { fill_shape<1, 8, 8><<<512, 256>>>(out, N, 1.f); }, 20), bytes);
     report("shape 256x16x4  k=2", time_it([&] { fill_shape<1, 16, 4><<<512, 256>>>(out, N, 1.f); }, 20), bytes);
     report("shape 256x32x2  k=2", time_it([&] { fill_shape<1, 32, 2><<<512, 256>>>(out, N, 1.f); }, 20), bytes);
