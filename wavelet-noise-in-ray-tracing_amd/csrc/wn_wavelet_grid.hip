@@ -45,6 +45,7 @@ struct BandArgs {
     float factor; // everything that scales this band's contribution: w[b] * out_scale / out_div
     int box_off;  // float offset of this band's coefficient box in dynamic LDS
     int r_off;    // float offset of this band's collapsed rows
+    int ex_cap;   // columns the LDS regions were sized for (the kernel never exceeds it)
 };
 
 struct SepArgs {
@@ -164,11 +165,11 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
         const int my0 = sgpr(s_mid[buf][b][0]), my1 = sgpr(s_mid[buf][b][kBrickY - 1]);
         const int mz0 = sgpr(s_mid[buf][b][8]), mz1 = sgpr(s_mid[buf][b][8 + BZ - 1]);
         o.ix0 = mx0 - 1;
-        o.ex = mx1 - mx0 + 4; // +3 support, +1 pad column (zero-weight tap)
+        o.ex = min(mx1 - mx0 + 4, a.band[b].ex_cap); // +3 support, +1 pad column (zero-weight tap)
         o.jy0 = my0 - 1;
-        o.ey = my1 - my0 + 3;
+        o.ey = min(my1 - my0 + 3, kBoxY); // the clamps never bind (plan_sep bounds the extents): memory safety
         o.kz0 = mz0 - 1;
-        o.nrows = (mz1 - mz0 + 3) * o.ey;
+        o.nrows = min(mz1 - mz0 + 3, kBoxZ) * o.ey;
         return o;
     };
 
@@ -256,12 +257,12 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
     auto phase1 = [&](int tb, int box_buf, int r_buf) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-            rs_[b] = (sgpr(s_mid[tb][b][17]) - sgpr(s_mid[tb][b][16]) + 4) | 1;
+            rs_[b] = min(sgpr(s_mid[tb][b][17]) - sgpr(s_mid[tb][b][16]) + 4, a.band[b].ex_cap) | 1;
         if (lane < rows) {
             const int yi = lane & (kBrickY - 1), zi = lane >> 3;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const int ex = sgpr(s_mid[tb][b][17]) - sgpr(s_mid[tb][b][16]) + 4;
+                const int ex = min(sgpr(s_mid[tb][b][17]) - sgpr(s_mid[tb][b][16]) + 4, a.band[b].ex_cap);
                 const int kz = s_mid[tb][b][8 + zi] - s_mid[tb][b][8];  // row's first box row in z
                 const int jy = s_mid[tb][b][yi] - s_mid[tb][b][0];      // ... and in y
                 float w9[3][3];
@@ -563,6 +564,7 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
         if (extent(kBrickY) > kBoxY || (!g.z_const_mode && extent(BZ) > kBoxZ)) return false;
         a->band[b].oscale = oscale[b];
         a->band[b].factor = (float)((double)(weights ? weights[b] : 1.0f) * (double)g.out_scale / (double)out_div);
+        a->band[b].ex_cap = exs[b];
         a->band[b].box_off = (int)box_total;
         box_total += (size_t)exs[b] * kColStride;
     }
