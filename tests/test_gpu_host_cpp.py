@@ -78,8 +78,9 @@ def test_scalar_members_match_reference_vectors(gold):
     assert (bits(vals[:, 5].astype(np.float32)) == bits(oracle.wavelet_texture_value(t3, True, 1.0, 4, f32))).all()
     assert (bits(vals[:, 6].astype(np.float32))
             == bits(oracle.noise_texture_value(oracle.perlin_perm(5489), 1.0, 4, f32))).all()
-    assert lines[len(pts)].split() == ["empty", "0", "0"]
-    assert lines[len(pts) + 1].split() == ["tile", "128", "coeffs", str(128 ** 3)]
+    assert lines[len(pts)].split() == ["batch_vs_scalar_mismatches", "0"]  # batched overloads, active mask
+    assert lines[len(pts) + 1].split() == ["empty", "0", "0"]
+    assert lines[len(pts) + 2].split() == ["tile", "128", "coeffs", str(128 ** 3)]
 
 
 def test_reference_experient_main_linked_against_this_library(tmp_path, shas):

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <vector>
 #include <algorithm>
+#include <array>
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -101,6 +102,37 @@ __global__ __launch_bounds__(256) void fill_policy(float *out, int N, float v)
     }
 }
 
+// store bursts separated by synthetic work: per brick `valu` dependent FMA steps per wave,
+// `lds` LDS read-modify-write steps, optional barrier -- what slows a store stream down?
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void fill_with_work(float *out, int N, float v, int valu, int lds, int barrier)
+{
+    __shared__ float sh[64 * WAVES * 4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xw = wave >> 2, wr = wave & 3;
+    const int nbx = N / (64 * WAVES), nby = N / 8, nbz = N / 8, nyz = nby * nbz;
+    const long long T = (long long)nbx * nyz;
+    int item = (int)(T * blockIdx.x / gridDim.x);
+    const int end = (int)(T * (blockIdx.x + 1) / gridDim.x);
+    float acc = v + lane;
+    sh[threadIdx.x] = acc;
+    for (; item < end; ++item) {
+        for (int i = 0; i < valu; ++i) acc = __builtin_fmaf(acc, 1.0001f, 0.5f);
+        for (int i = 0; i < lds; ++i) {
+            sh[threadIdx.x] = acc;
+            acc += sh[(threadIdx.x + 17 * (i + 1)) % (64 * WAVES)];
+        }
+        if (barrier) __syncthreads();
+        const int bx = item / nyz, yz = item - bx * nyz, bz = yz / nby, by = yz - bz * nby;
+        for (int row = wr; row < 64; row += 4) {
+            const int y = by * 8 + (row & 7), z = bz * 8 + (row >> 3);
+            v4f x = v4f{acc, v + row, v + 2, v + 3};
+            v4f *dst = reinterpret_cast<v4f *>(out + ((size_t)z * N + y) * N + bx * 64 * WAVES + xw * 256) + lane;
+            *dst = x;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void copy_linear(const float4 *in, float4 *out, size_t n4)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = in[i];
@@ -144,6 +176,13 @@ int main()
         report(nm, time_it([&] { fill_bricks_persistent<false><<<256 * k, 256>>>(out, N, 1.f); }, 20), bytes);
         snprintf(nm, 64, "fill_bricks_persistent k=%d nt", k);
         report(nm, time_it([&] { fill_bricks_persistent<true><<<256 * k, 256>>>(out, N, 1.f); }, 20), bytes);
+    }
+    for (int k : {1, 2}) {
+        char nm[96];
+        for (auto cfg : {std::array<int,3>{0,0,0}, std::array<int,3>{0,0,1}, std::array<int,3>{400,0,1}, std::array<int,3>{1600,0,1}, std::array<int,3>{0,200,1}, std::array<int,3>{400,200,1}}) {
+            snprintf(nm, 96, "work 8w k=%d valu=%d lds=%d bar=%d", k, cfg[0], cfg[1], cfg[2]);
+            report(nm, time_it([&] { fill_with_work<8><<<256 * k, 512>>>(out, N, 1.f, cfg[0], cfg[1], cfg[2]); }, 10), bytes);
+        }
     }
     report("policy plain    k=2", time_it([&] { fill_policy<0><<<512, 256>>>(out, N, 1.f); }, 20), bytes);
     report("policy sc1      k=2", time_it([&] { fill_policy<1><<<512, 256>>>(out, N, 1.f); }, 20), bytes);

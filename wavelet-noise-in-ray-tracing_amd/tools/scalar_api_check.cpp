@@ -5,6 +5,7 @@
 //
 // stdin: N, then N lines "x y z";  stdout: one line per point:
 //   e2d e3d e3dp(normal 0,0,1) perlin12345(x,y,z as double) fractal(vec3) tex_wavelet3d(1.0,4) tex_perlin(1.0,4)
+#include <cstdint>
 #include <cstdio>
 #include <iostream>
 #include <memory>
@@ -32,6 +33,32 @@ int main()
             std::printf("%.9g %.9g %.9g %.17g %.17g %.9g %.9g\n", n2.evaluate2D(p), n3.evaluate3D(p),
                         n3.evaluate3DProjected(p, normal), per.noise((double)p[0], (double)p[1], (double)p[2]),
                         per.fractal_noise(q), wt->value(0, 0, q).x(), pt->value(0, 0, q).x());
+        }
+        // batched overloads must return exactly what the scalar members return
+        {
+            std::vector<float> b3(n), b2(n), xy(2 * n), grey(n, -7.0f), greyp(n, -7.0f);
+            std::vector<uint8_t> active(n);
+            for (size_t i = 0; i < n; ++i) {
+                xy[2 * i] = pts[3 * i];
+                xy[2 * i + 1] = pts[3 * i + 1];
+                active[i] = (uint8_t)(i % 3 != 0);
+            }
+            n3.evaluate3D(pts.data(), n, b3.data());
+            n2.evaluate2D(xy.data(), n, b2.data());
+            auto *wtex = dynamic_cast<wavelet_texture *>(wt.get());
+            auto *ptex = dynamic_cast<noise_texture *>(pt.get());
+            wtex->values(pts.data(), active.data(), n, grey.data());
+            ptex->values(pts.data(), active.data(), n, greyp.data());
+            size_t bad = 0;
+            for (size_t i = 0; i < n; ++i) {
+                const float *p = &pts[3 * i];
+                const point3 q(p[0], p[1], p[2]);
+                bad += b3[i] != n3.evaluate3D(p);
+                bad += b2[i] != n2.evaluate2D(p);
+                bad += grey[i] != (active[i] ? wt->value(0, 0, q).x() : -7.0f);
+                bad += greyp[i] != (active[i] ? pt->value(0, 0, q).x() : -7.0f);
+            }
+            std::printf("batch_vs_scalar_mismatches %zu\n", bad);
         }
         // conventions: an un-generated object evaluates to 0 (WaveletNoise.cpp:112,186,219)
         std::printf("empty %.9g %.9g\n", empty.evaluate3D(&pts[0]), empty.evaluate2D(&pts[0]));
