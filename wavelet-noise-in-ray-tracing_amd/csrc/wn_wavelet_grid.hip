@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
     constexpr int kRowsPerWave = (kBoxY * kBoxZ + kWaves - 1) / kWaves;
     constexpr int kColGroups = (kBrickX / 3 + 8 + 63) / 64; // 64-column groups a box can span (step <= 1/3)
     float pf[kRowsPerWave][kColGroups];
-    auto issue_box = [&](int buf, int b) {
+    auto issue_box = [&](int buf, int b) -> Box {
         const Box o = box_of(buf, b);
         int k = 0, j = wave;
 #pragma unroll
@@ -195,9 +195,9 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
             }
             j += kWaves;
         }
+        return o; // geometry stays in SGPRs for commit_box
     };
-    auto commit_box = [&](int buf, int b, int box_buf) {
-        const Box o = box_of(buf, b);
+    auto commit_box = [&](const Box &o, int b, int box_buf) {
         float *col = lds + a.band[b].box_off + box_buf * a.box_buf_stride + lane * kColStride;
         int k = 0, j = wave;
 #pragma unroll
@@ -320,12 +320,19 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
         float *zrow = a.out + ((size_t)z_base * g.ny + y_base + wr) * g.nx + (size_t)bx * kBrickX + xw * 256;
         if (full) {
             // interior brick: every wave store is one 1-KiB global_store_dwordx4
-            for (int zi = 0; zi < BZ; ++zi, zrow += plane) {
+            auto two_rows = [&]() {
                 float acc[4];
                 row_values(acc);
                 reinterpret_cast<v4f *>(zrow)[lane] = v4f{acc[0], acc[1], acc[2], acc[3]};
                 row_values(acc);
                 reinterpret_cast<v4f *>(zrow + 4 * (size_t)g.nx)[lane] = v4f{acc[0], acc[1], acc[2], acc[3]};
+                zrow += plane;
+            };
+            if (a.bz_log2 == 3) { // the common case, straight-line: LDS reads of later rows are hoisted over earlier FMAs
+#pragma unroll
+                for (int zi = 0; zi < 8; ++zi) two_rows();
+            } else {
+                for (int zi = 0; zi < BZ; ++zi) two_rows();
             }
         } else {
             for (int zi = 0; zi < BZ; ++zi, zrow += plane) {
@@ -372,8 +379,8 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
     if (item + 1 < item_end) fill_tables(1, n1x, n1y, n1z);
     __syncthreads();
     if (NB == 1) {
-        issue_box(0, 0);
-        commit_box(0, 0, 0);
+        const Box o0 = issue_box(0, 0);
+        commit_box(o0, 0, 0);
     }
     x_weights(0);
     int weights_bx = bx;
@@ -386,17 +393,18 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
         next_brick(n2x, n2y, n2z);
 
         if (NB == 1) {
-            if (has_next) issue_box(tb1, 0);
+            Box onext{};
+            if (has_next) onext = issue_box(tb1, 0);
             phase1(tb, par, par);
-            if (has_next) commit_box(tb1, 0, par ^ 1);
+            if (has_next) commit_box(onext, 0, par ^ 1);
             if (item + 2 < item_end) fill_tables(tb2, n2x, n2y, n2z);
             __syncthreads();
             phaseC(par);
         } else {
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                issue_box(tb, b);
-                commit_box(tb, b, 0);
+                const Box ob = issue_box(tb, b);
+                commit_box(ob, b, 0);
             }
             __syncthreads(); // boxes complete; previous phase C done (R free)
             phase1(tb, 0, 0);
