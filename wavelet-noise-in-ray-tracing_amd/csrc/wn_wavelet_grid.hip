@@ -2,18 +2,18 @@
 //
 // Two kernels stand under wn_eval3d_grid / wn_multiband3d_grid:
 //
-//  * grid3d_sep_kernel<NB>  (default).  A dense lattice is axis-aligned, so the 27-tap sum of
+//  * grid3d_sep_kernel<NB, XW>  (default).  A dense lattice is axis-aligned, so the 27-tap sum of
 //    WaveletNoise::evaluate3D (WaveletNoise.cpp:202-213) factors per axis:
 //        out[x,y,z] = sum_i Wx[x,i] * ( sum_j Wy[y,j] * ( sum_k Wz[z,k] * C[i,j,k] ) ).
-//    One workgroup (4 waves) owns a brick of 256 x BY x BZ samples.  It stages the brick's
-//    coefficient box (with the periodic wrap resolved) through LDS, collapses y and z for every
-//    sample row into LDS rows R[row][i] (9 FMAs per coefficient column), then each lane
+//    Persistent workgroups (4*XW waves) walk bricks of 256*XW x 8 x BZ samples.  Per brick the
+//    coefficient box (periodic wrap resolved) is staged through LDS, y and z are collapsed for
+//    every sample row into LDS rows R[row][i] (9 FMAs per coefficient column), then each lane
 //    produces 4 consecutive x samples per row from a 4-wide window of R with its 16 window
 //    weights held in registers, and stores one float4: every wave store is 1 KiB contiguous.
 //    Per-axis weights/mids are computed exactly as the reference does; only the order of the
-//    final sums differs (<= ~1e-6 abs; tolerance 1e-5).  NB > 1 accumulates NB bands in-kernel
-//    (Cook & DeRose WMultibandNoise) with one store.
-//    Bound: HBM write stream, 4 B/sample (+ the 8 MiB tile, read once, L2/MALL resident).
+//    final sums differs (measured <= 1.5e-6 abs; tolerance 1e-5).  NB > 1 accumulates NB bands
+//    in-kernel (Cook & DeRose WMultibandNoise) with one store.
+//    Bound: HBM write stream, 4 B/sample (+ the 8 MiB tile, read ~twice, L2/MALL resident).
 //
 //  * grid3d_direct_kernel (WN_GRID_EXACT, or lattices the brick scheme does not cover: step
 //    > 1/3 cell per sample, negative steps).  One sample per lane, the reference's loop order
@@ -173,9 +173,9 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
         return o;
     };
 
-    // Box rows are (k, j) pairs, r = k*ey + j; wave w takes rows w, w+4, ...: the row part of every
-    // address is scalar, a lane contributes only its column.  Columns 0..63 in `pf`, the (at most
-    // 27) columns from 64 on in `pfx`.
+    // Box rows are (k, j) pairs, r = k*ey + j; wave w takes rows w, w+kWaves, ...: the row part of every
+    // address is scalar, a lane contributes only its column (256-B coalesced reads); a box spans up
+    // to kColGroups groups of 64 columns, pf[t][c] holds row t of this wave, column group c.
     constexpr int kRowsPerWave = (kBoxY * kBoxZ + kWaves - 1) / kWaves;
     constexpr int kColGroups = (kBrickX / 3 + 8 + 63) / 64; // 64-column groups a box can span (step <= 1/3)
     float pf[kRowsPerWave][kColGroups];
