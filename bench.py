@@ -135,7 +135,11 @@ def main():
         else:
             exact = args.workload == "wavelet3d_exact"
             step = lambda: wn.wavelet_volume(noise, n, n, n, z0, z1, OCTAVE, exact=exact, out=out)  # noqa: E731
-            kernel = "grid3d_direct_kernel" if exact else "grid3d_sep_kernel<NB=1>"
+            # the library's dispatch (csrc/wn_wavelet_strip.hip strip_try): rows of k*256 samples and
+            # 0.18 <= planes per lattice step <= 1/3 go to the strip-march kernel, other lattices to the brick kernel
+            lattice_step = 4.0 * 2.0 ** OCTAVE * 2.0 / n
+            strip = n % 256 == 0 and 0.18 <= lattice_step < 1.0 / 3.0
+            kernel = "grid3d_direct_kernel" if exact else ("grid3d_strip_kernel" if strip else "grid3d_sep_kernel<NB=1>")
             desc = (f"{n}^3 dense 3D WNoise grid, tile={TILE}, octave={OCTAVE} (configs[1])" if planes == n else
                     f"{n}x{n}x{planes} z-slab per GPU of a {n}^2 x {planes}*N lattice, tile={TILE}, octave={OCTAVE} (configs[4] shard)")
     elif args.workload in ("turb7", "perlin"):

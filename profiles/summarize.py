@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
-KERNEL = "grid3d_sep_kernel"
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "grid3d_strip_kernel"  # the kernel bench.py's default workload launches
 
 for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
     shutil.copyfile(f, os.path.join(dst, f"{tag}_kernel_stats_bench_wavelet3d.csv"))

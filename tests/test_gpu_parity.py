@@ -186,6 +186,37 @@ def test_brick_path_vs_oracle(wn, ora, noise3, tile3d_128, den, nx, ny, z0, z1, 
     assert (bits(exact) == bits(want)).all()
 
 
+@pytest.mark.parametrize("den,nx,ny,z0,z1,octave", [
+    (512, 256, 4, 0, 300, 4),       # three z chunks of 100 planes, one column block
+    (512, 512, 3, 17, 18, 4),       # a single plane
+    (400, 512, 6, 0, 40, 4),        # step .32, close to the 1/3 limit of the window scheme
+    (700, 768, 5, 0, 20, 4),        # step .183, just inside the regime; inexact division; 3 column blocks
+    (512, 1024, 3, 100, 140, 4),    # x beyond one lattice period
+    (512, 512, 2, 8190, 8200, 4),   # large z offset
+])
+def test_strip_path_vs_oracle(wn, ora, noise3, tile3d_128, den, nx, ny, z0, z1, octave):
+    """Lattices in the strip-march kernel's regime (rows of k*256 samples, 0.18 <= step <= 1/3):
+    chunk seams, single planes, the regime's edges."""
+    want = ora.grid_wavelet3d_volume(tile3d_128, den, nx, ny, z0, z1, octave)
+    fast = host(wn.wavelet_volume(noise3, den, nx, ny, z0, z1, octave))
+    assert fast.shape == want.shape
+    err = np.abs(fast - want).max()
+    assert err <= TOL, err
+
+
+@pytest.mark.parametrize("den,nx,ny,z0,z1", [
+    (512, 512, 300, 0, 512),        # 2400 items on 2048 wave slots: second-round items change segment
+    (512, 768, 170, 3, 260),        # ragged last chunk, 3 column blocks, odd row count
+])
+def test_strip_path_many_items_vs_exact_kernel(wn, noise3, den, nx, ny, z0, z1):
+    """More items than resident compute waves.  Checker: the exact kernel (bit-identical to the oracle,
+    test_brick_path_vs_oracle) on the same lattice."""
+    fast = wn.wavelet_volume(noise3, den, nx, ny, z0, z1, 4)
+    exact = wn.wavelet_volume(noise3, den, nx, ny, z0, z1, 4, exact=True)
+    err = float((fast - exact).abs().max())
+    assert err <= TOL, err
+
+
 def test_brick_path_small_tiles_and_wrap(wn, ora, gold):
     """Periodic wrap inside the coefficient box: tiles far smaller than a brick's footprint."""
     for key in ("tile3d_8_7", "tile3d_16_12345", "tile3d_5odd_11"):

@@ -84,6 +84,9 @@ struct GridArgs {
 
 int check_grid(const wn_grid *g, bool needs_z, GridArgs *out);
 
+// wn_wavelet_strip.hip: launches the strip-march kernel when the lattice is in its regime.
+int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_t stream, bool *launched);
+
 // wn_tilegen.hip: the filter half of generateNoiseTile2D/3D on the device.
 int tilegen_filter(wn_tile *t, const float *field_dev, hipStream_t stream);
 // wn_tilegen.hip: (re)build t->dev_padded from t->dev (no-op for 2-D tiles).

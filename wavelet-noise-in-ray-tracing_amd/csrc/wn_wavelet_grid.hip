@@ -696,6 +696,9 @@ int wn_eval3d_grid(const wn_tile *tile, const wn_grid *grid, float *out_dev, voi
     if (!out_dev) return fail(WN_ERR_INVALID, "out_dev is NULL");
 
     if (!(grid->flags & WN_GRID_EXACT)) {
+        bool launched = false;
+        rc = strip_try(tile, g, out_dev, as_stream(stream), &launched); // rows of k*256 samples, >= 0.18 planes per step
+        if (rc || launched) return rc;
         SepArgs a{};
         size_t lds = 0;
         const float os = g.octave_scale;
