@@ -2,7 +2,7 @@
 // multiple of 256 samples: the store-stream-shaped variant of the separable evaluation
 //     out[x,y,z] = sum_i Wx[x,i] * ( sum_k Wz[z,k] * ( sum_j Wy[y,j] * C[i,j,k] ) ).
 //
-// What shapes it (profiles/r01_store_ceiling_microbench.txt, DESIGN.md "store stream"):
+// What shapes it (profiles/r01d_store_stream_microbench.txt, DESIGN.md "store stream"):
 //   * the fastest fp32 store stream on an MI355X (6.2-6.5 TB/s, the pattern of hipMemset's own
 //     kernel) has waves that each issue ONE 1-KiB store per step, the whole chip writing a
 //     contiguous stretch of rows per step and every wave returning to the same slot of the next

@@ -415,7 +415,7 @@ int main(int argc, char **)
         report(nm, time_it([&] { fill_decoupled<8, 4><<<256, 768>>>(out, N, 1.f, fma); }, 20), bytes);
         snprintf(nm, 64, "decoupled 8c+8s fma=%d", fma);
         report(nm, time_it([&] { fill_decoupled<8, 8><<<256, 1024>>>(out, N, 1.f, fma); }, 20), bytes);
-        snprintf(nm, 64, "decoupled 4c+4s fma=%d (z whole)", fma);
+        snprintf(nm, 64, "decoupled 4c+4s fma=%d (2 WG per CU)", fma);
         report(nm, time_it([&] { fill_decoupled<4, 4><<<512, 512>>>(out, N, 1.f, fma); }, 20), bytes);
         snprintf(nm, 64, "decoupled ring 8c+4s K=8 fma=%d", fma);
         report(nm, time_it([&] { fill_decoupled_ring<8, 4, 8><<<256, 768>>>(out, N, 1.f, fma); }, 20), bytes);
