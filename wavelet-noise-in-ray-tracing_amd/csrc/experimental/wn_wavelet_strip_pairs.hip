@@ -1,8 +1,13 @@
+// experimental/wn_wavelet_strip_pairs.hip -- NOT part of libwnoise_hip.so.  Round-1 predecessor of
+// ../wn_wavelet_strip.hip kept for reference: one compute wave + one store wave per workgroup, each item (one
+// row segment x <= 128 planes) fills its own y-collapsed coefficient table.  512^3: 112-118 us; its table
+// fills read three times the bytes of the row-group kernel that replaced it (12 us at kernel start, 20-30 us
+// for the second item of a wave while the rest of the chip is storing).
 // wn_wavelet_strip.hip -- "strip march" kernel for dense 3-D wavelet lattices whose rows are a
 // multiple of 256 samples: the store-stream-shaped variant of the separable evaluation
 //     out[x,y,z] = sum_i Wx[x,i] * ( sum_k Wz[z,k] * ( sum_j Wy[y,j] * C[i,j,k] ) ).
 //
-// What shapes it (profiles/r01d_store_stream_microbench.txt, DESIGN.md "Store stream"):
+// What shapes it (profiles/r01d_store_stream_microbench.txt, DESIGN.md "store stream"):
 //   * the fastest fp32 store stream on an MI355X (6.2-6.5 TB/s, the pattern of hipMemset's own
 //     kernel) has waves that each issue ONE 1-KiB store per step, the whole chip writing a
 //     contiguous stretch of rows per step and every wave returning to the same slot of the next
@@ -14,34 +19,31 @@
 //   * waves that only store, fed through LDS by waves that only compute, with an LDS-only barrier
 //     per step (__syncthreads() would drain vmcnt, i.e. wait for the stores), keep the store stream
 //     at its floor while the compute side runs beside it.
-// So a workgroup is 4 compute waves + 4 store waves, two workgroups per CU.
-//   * An item is four consecutive rows y..y+3 of one 256-sample column block (x0..x0+255) times a
-//     chunk of <= 128 planes; compute wave w owns row y+w and marches through the planes z.
-//   * The four rows share 4 tile rows per coefficient plane.  The compute waves together first read
-//     everything the item touches -- <= 38 planes x 4 tile rows x 96 columns, aligned 16-byte loads,
-//     8 in flight per lane -- into an LDS table: the march itself issues no global load.  (Reads
-//     that compete with a saturated store stream take 5-10 us to return.)
+// So a workgroup is ONE compute wave + ONE store wave (a 2-wave barrier couples nothing else), eight
+// workgroups per CU.
+//   * An item is a 256-sample row segment (y, x0..x0+255) times a chunk of <= 128 planes.  The
+//     compute wave first reads ALL coefficients the item touches -- 3 tile rows x <= 96 columns x the
+//     <= 38 planes of the chunk, as aligned 16-byte loads, 24 in flight per lane -- collapses them
+//     along y with the item's fixed wy weights and keeps Y[plane][column] in LDS: the march itself
+//     issues no global load.
 //   * March, one plane per step, lane = coefficient column: the y-collapsed planes of the three z
-//     taps live in registers -- at a plane change the wave collapses its three table rows of the
-//     plane after next with its fixed wy weights -- R[column] = sum_k wz[k]*Y[k] goes through a
-//     per-wave LDS row so that each lane can read the 4-wide window of its 4 x samples, 16 window
-//     FMAs, and the 1-KiB output row is parked in LDS.  Software-pipelined: R rows are written two
-//     planes ahead, window and z-table reads are issued a step before their use.
-//   * The store wave paired with the compute wave moves each parked row to memory.  The barrier of
-//     step z sits in the middle of step z+1 and shares a statement with that step's R write, with a
-//     counted lgkmcnt: no LDS latency is waited out at the barrier.
-//   * The two workgroups of a CU swap wave priority between their two items (s_setprio): the
-//     arbiter otherwise favours the older workgroup all the way, which then finishes 15-20 us early
-//     and leaves the CU half empty (111 -> 104 us at 512^3).
+//     taps live in registers (the next one prefetched from LDS), R[column] = sum_k wz[k]*Y[k] goes
+//     through a per-wave LDS row so that each lane can read the 4-wide window of its 4 x samples, 16
+//     window FMAs, and the 1-KiB output row is parked in LDS.  Software-pipelined: R rows are
+//     written two planes ahead, window and z-table reads are issued a step before their use.
+//   * The store wave moves each parked row to memory.  The barrier of step z sits in the middle of
+//     step z+1 and shares a statement with that step's R write, with a counted lgkmcnt: no LDS
+//     latency is waited out at the barrier.
+// Measured (512^3, octave 4): march phases run at the store floor (175-350 ns per plane and wave);
+// what remains above it is the two table fills per wave (12 us at kernel start, 20-30 us when they
+// compete with other waves' stores).  Finer lattices (< 0.18 planes per step) amortise the brick
+// kernel's staging better and stay there.
 // Per-axis mids / weights are computed exactly as the reference does (WaveletNoise.cpp:194-200);
 // only the order of the final sums differs (tolerance 1e-5, like the brick kernel).
-#include "wn_internal.hpp"
+#include "../wn_internal.hpp"
 
 #include <algorithm>
 #include <cmath>
-#ifdef WN_STRIP_STAMPS
-#include <cstdio>
-#endif
 
 namespace {
 
@@ -49,18 +51,18 @@ using wn::GridArgs;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int kCW = 4;          // compute waves per workgroup = rows per item
+constexpr int kCW = 1;          // compute waves per workgroup
 constexpr int kSW = kCW;        // store waves per workgroup (one per compute wave)
 constexpr int kCols = 96;       // coefficient columns an item may touch (host: 255*step + 7 <= 96)
 constexpr int kPlanes = 38;     // coefficient planes an item may touch (host: (chunk_len-1)*step + 5 <= 38)
-constexpr int kRowFloats = 96;  // table row = kCols
 constexpr int kMaxChunk = 128;  // planes per item
 constexpr int kRRow = 100;      // one R row (96 columns + pad)
-constexpr int kTableFloats = kPlanes * kCW * kRowFloats; // the item's coefficient table [plane][tile row 0..3][96]
+constexpr int kWaveFloats = kPlanes * kCols + 2 * kRRow + 4 * (kMaxChunk + 3); // Y, 2 R rows, z table
 constexpr int kStageFloats = 2 * kCW * 256; // two steps x one 1-KiB output row per compute wave
-constexpr int kZtabFloats = 4 * (kMaxChunk + 3);
-constexpr size_t kLdsBytes = (size_t)(kTableFloats + kStageFloats + kCW * 2 * kRRow + kZtabFloats) * sizeof(float);
-static_assert(2 * kLdsBytes <= 160 * 1024, "two workgroups share a CU");
+constexpr size_t kLdsBytes = (size_t)(kCW * kWaveFloats + kStageFloats) * sizeof(float);
+constexpr int kWgPerCu = 8 / kCW;
+static_assert(kWgPerCu * kLdsBytes <= 160 * 1024, "the workgroups of a CU share its LDS");
+static_assert(kWaveFloats % 4 == 0 && kCols % 4 == 0 && kRRow % 4 == 0, "16-byte aligned sub-arrays");
 
 struct StripArgs {
     const float *coef;
@@ -69,12 +71,9 @@ struct StripArgs {
     GridArgs g;
     float inv_den;    // 1/den when den is a power of two (exact), else 0
     int segs_per_row; // nx / 256
-    int total_groups; // segs_per_row * ceil(ny / 4): groups of four rows of one column block
+    int total_segs;   // segs_per_row * ny
     int chunk_len;    // planes per item
-    int total_items;  // total_groups * number of z chunks
-#ifdef WN_STRIP_STAMPS
-    unsigned long long *stamps; // debug build: phase time stamps of a few workgroups
-#endif
+    int total_items;  // total_segs * number of z chunks
 };
 
 __device__ __forceinline__ float coord(int i, float den, float inv_den, float range, float oscale, float post)
@@ -96,46 +95,29 @@ __device__ __forceinline__ unsigned lds_address(const float *p)
 // store wave wait for its outstanding global stores.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// The first half of the grid (dispatched first, one workgroup per CU) and the second half share the CUs; they
-// take turns at the higher wave priority, item by item.
-__device__ __forceinline__ void set_round_priority(int round)
-{
-    if (((blockIdx.x >= gridDim.x / 2) ^ (round & 1)) != 0) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-}
-
 __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const StripArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GridArgs &g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // LDS: the item's coefficient table [plane][tile row 0..3][96], the output stage
-    // [step parity][compute wave][256], per compute wave two R rows, the z table of the item
-    float *const table = lds;
-    float *const stage = table + kTableFloats;
-    float *const rrows = stage + kStageFloats;
-    float *const ztab = rrows + kCW * 2 * kRRow; // per plane of the item {mid_z, wz0, wz1, wz2}, + 3 pad entries
+    float *stage = lds + kCW * kWaveFloats; // [step parity][compute wave][256 floats]
     const size_t plane_stride = (size_t)g.ny * g.nx;
-    // Every wave of the workgroup passes the same barriers.  Per round (= item): one after the item's
-    // set-up, one per plane of a full chunk, one closing the round.  Plane t: compute wave c parks its row
-    // in stage[t&1][c]; after the barrier store wave c moves it to memory while the compute waves are on t+1.
-    const int rounds = (a.total_items + gridDim.x - 1) / gridDim.x;
+    // Every wave of the workgroup passes the same barriers: rounds of chunk_len steps (+1 closing the
+    // round).  Step t of a round: compute wave c parks its row in stage[t&1][c]; after the barrier the
+    // store wave moves it to memory while the compute wave is on step t+1.
+    const int rounds = (a.total_items + gridDim.x * kCW - 1) / (gridDim.x * kCW);
 
     if (wave >= kCW) {
         // ---- store waves: no arithmetic, no loads --------------------------------------------------------
         const int c = wave - kCW;
         for (int round = 0; round < rounds; ++round) {
-            set_round_priority(round);
-            const int item = round * gridDim.x + blockIdx.x;
-            const int chunk = item / a.total_groups, grp = item - chunk * a.total_groups;
-            const int yg = grp / a.segs_per_row, xs = grp - yg * a.segs_per_row;
+            const int item = (round * gridDim.x + blockIdx.x) * kCW + c;
+            const int chunk = item / a.total_segs, seg = item - chunk * a.total_segs;
             const int zb = chunk * a.chunk_len;
-            const int row = yg * kCW + c; // the last group of a lattice with ny % 4 != 0 has rows past the end: computed, not stored
-            const int zn = (item < a.total_items && row < g.ny) ? min(a.chunk_len, g.nz - zb) : 0;
-            float *dst = a.out + ((size_t)zb * plane_stride + (size_t)row * g.nx + xs * 256 + lane * 4);
+            const int zn = item < a.total_items ? min(a.chunk_len, g.nz - zb) : 0;
+            float *dst = a.out + ((size_t)zb * plane_stride + (size_t)seg * 256 + lane * 4); // seg*256 == y*nx + xs*256
             const float *src = stage + c * 256 + lane * 4;
-            lds_barrier(); // set-up
             for (int t = 0; t < a.chunk_len; ++t) {
                 lds_barrier();
                 if (t < zn) {
@@ -143,60 +125,53 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
                     dst += plane_stride;
                 }
             }
-            lds_barrier(); // round closed: stage and z table may be rewritten
+            lds_barrier(); // round closed: the stage may be rewritten
         }
         return;
     }
 
     // ---- compute waves ---------------------------------------------------------------------------------
-#ifdef WN_STRIP_STAMPS
-    int sidx = 0;
-    auto stamp = [&]() { if (a.stamps && tid == 0 && (blockIdx.x % 65) == 0 && sidx < 16) a.stamps[(blockIdx.x / 65) * 16 + sidx] = wall_clock64(); ++sidx; };
-#else
-    auto stamp = [] {};
-#endif
-    stamp();
-    float *const rb0 = rrows + wave * 2 * kRRow;
+    float *const ytab = lds + wave * kWaveFloats;  // [plane][kCols]
+    float *const rb0 = ytab + kPlanes * kCols, *const rb1 = rb0 + kRRow;
+    float *const ztab = rb1 + kRRow;               // per plane of the item {mid_z, wz0, wz1, wz2}
     const v4f *const zt = reinterpret_cast<const v4f *>(ztab);
     const float den = (float)g.den;
     const int n = a.n, mask = a.nmask;
+    // per-segment state, kept across the rounds of a wave (consecutive items of a wave usually are chunks of
+    // the same segment)
+    int prev_seg = -1;
+    float ww[4][4] = {};
+    int wbase = 0, ix0 = 0, my = 0, nquads = kCols / 4;
+    float wy0 = 0.0f, wy1 = 0.0f, wy2 = 0.0f;
     for (int round = 0; round < rounds; ++round) {
-        set_round_priority(round);
-        const int item = round * gridDim.x + blockIdx.x;
+        const int item = (round * gridDim.x + blockIdx.x) * kCW + wave;
         if (item >= a.total_items) { // same barriers, no work
-            for (int t = 0; t <= a.chunk_len + 1; ++t) lds_barrier();
+            for (int t = 0; t <= a.chunk_len; ++t) lds_barrier();
             continue;
         }
-        const int chunk = item / a.total_groups, grp = item - chunk * a.total_groups;
-        const int yg = grp / a.segs_per_row, xs = grp - yg * a.segs_per_row;
+        const int chunk = item / a.total_segs, seg = item - chunk * a.total_segs;
         const int zb = chunk * a.chunk_len, zn = min(a.chunk_len, g.nz - zb);
-        const int y = yg * kCW + wave;
-        const int x_first = xs * 256, x0 = x_first + lane * 4;
 
-        // ---- z table of the item (the four compute waves together); 3 pad entries repeat the last plane
-        for (int i = tid; i < zn + 3; i += 64 * kCW) {
-            int m;
-            float w0, w1, w2;
-            wn::bspline(coord(g.z0 + zb + min(i, zn - 1), den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), m, w0, w1, w2);
-            *reinterpret_cast<v4f *>(ztab + 4 * i) = v4f{__int_as_float(m), w0 * g.out_scale, w1 * g.out_scale, w2 * g.out_scale};
-        }
-        // ---- x: this lane's four samples -> 16 window weights, window start as a column index ------
-        int mx_first;
-        {
-            float t0, t1, t2;
-            wn::bspline(coord(x_first, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), mx_first, t0, t1, t2);
-            mx_first = __builtin_amdgcn_readfirstlane(mx_first);
-        }
-        const int ix0 = (mx_first - 1) & ~3; // coefficient column of table/R column 0, aligned for 16-byte loads
-        float ww[4][4];
-        int wbase;
-        {
+        if (seg != prev_seg) {
+            prev_seg = seg;
+            const int y = seg / a.segs_per_row, xs = seg - y * a.segs_per_row;
+            const int x_first = xs * 256, x0 = x_first + lane * 4;
+            // ---- x: this lane's four samples -> 16 window weights, window start as a column index --
+            int mx_first;
+            {
+                float t0, t1, t2;
+                wn::bspline(coord(x_first, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), mx_first, t0, t1, t2);
+                mx_first = __builtin_amdgcn_readfirstlane(mx_first);
+            }
+            ix0 = (mx_first - 1) & ~3; // coefficient column of Y/R column 0, aligned for 16-byte loads
             int m[4];
             float w[4][3];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 wn::bspline(coord(x0 + q, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), m[q], w[q][0], w[q][1], w[q][2]);
             wbase = min(m[0] - 1 - ix0, kCols - 4); // the host guarantees m[0] + 2 - ix0 < kCols
+            // column quads the segment touches: lane 63 holds the last window
+            nquads = min(__builtin_amdgcn_readlane(wbase, 63) / 4 + 2, kCols / 4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const bool up = m[q] != m[0]; // mid is m[0] or m[0]+1 (host guarantees step <= 1/3)
@@ -205,64 +180,74 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
                 ww[q][2] = up ? w[q][1] : w[q][2];
                 ww[q][3] = up ? w[q][2] : 0.0f;
             }
+            // ---- y: fixed for the segment ----------------------------------------------------------
+            int my_v;
+            wn::bspline(coord(y, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), my_v, wy0, wy1, wy2);
+            my = __builtin_amdgcn_readfirstlane(my_v);
         }
-        // ---- y: the item's rows y0..y0+3 have mids my_first or my_first+1 (host: 3 steps span < 1), so the
-        // four tile rows my_first-1 .. my_first+2 serve all of them; this wave's three start at row d.
-        int my_first, my_v, m0;
-        float wy0, wy1, wy2;
-        {
-            float t0, t1, t2;
-            wn::bspline(coord(yg * kCW, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), my_first, t0, t1, t2);
-            wn::bspline(coord(g.z0 + zb, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), m0, t0, t1, t2);
-        }
-        wn::bspline(coord(y, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), my_v, wy0, wy1, wy2);
-        my_first = __builtin_amdgcn_readfirstlane(my_first);
-        m0 = __builtin_amdgcn_readfirstlane(m0);
-        const int d = min(max(__builtin_amdgcn_readfirstlane(my_v) - my_first, 0), 1);
 
-        // ---- coefficient table of the item: planes m0-1 .. m_last+1, tile rows my_first-1 .. my_first+2,
-        // columns ix0 .. ix0+95, filled by the four compute waves together (16 bytes per lane and load, aligned:
-        // no wrap inside a quad)
-        int m_last;
+        // ---- all coefficients of the item -> Y[plane][column] in LDS ----------------------------------
+        // planes m0-1 .. m_last+1 (m0, m_last: mids of the first and last plane of the chunk)
+        int m0, m_last;
         {
             float t0, t1, t2;
+            wn::bspline(coord(g.z0 + zb, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), m0, t0, t1, t2);
             wn::bspline(coord(g.z0 + zb + zn - 1, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), m_last, t0, t1, t2);
+            m0 = __builtin_amdgcn_readfirstlane(m0);
             m_last = __builtin_amdgcn_readfirstlane(m_last);
         }
         const int planes = min(m_last - m0 + 3, kPlanes); // the host guarantees the bound
         {
-            constexpr int kBatch = 8, kQuads = kCols / 4;
-            const int total = planes * kCW * kQuads; // (plane, tile row, quad) triples
-            for (int q0 = 0; q0 < total; q0 += kBatch * 64 * kCW) {
-                v4f c[kBatch];
-                int dst[kBatch];
+            // lane = (plane parity, column quad): 24 quads of 4 columns, two planes per pass, kBatch passes
+            // of loads in flight; lanes past the 24 quads repeat quad 23, passes past the last plane repeat
+            // it (duplicate writes of equal values)
+            constexpr int kBatch = 8;
+            const int sub = lane >> 5, quad = min(lane & 31, nquads - 1);
+            const size_t col = (size_t)((ix0 + 4 * quad) & mask); // aligned: no wrap inside a quad
+            const float *row0 = a.coef + (size_t)((my - 1) & mask) * n + col;
+            const float *row1 = a.coef + (size_t)(my & mask) * n + col;
+            const float *row2 = a.coef + (size_t)((my + 1) & mask) * n + col;
+            for (int pb = 0; pb < planes; pb += 2 * kBatch) {
+                v4f c[kBatch][3];
 #pragma unroll
                 for (int k = 0; k < kBatch; ++k) {
-                    const int q = min(q0 + k * 64 * kCW + tid, total - 1); // past the end: repeat the last triple
-                    const int p = q / (kCW * kQuads), rq = q - p * (kCW * kQuads), row = rq / kQuads, quad = rq - row * kQuads;
-                    const size_t src = (size_t)((m0 - 1 + p) & mask) * n * n + (size_t)((my_first - 1 + row) & mask) * n
-                                       + (size_t)((ix0 + 4 * quad) & mask);
-                    c[k] = *reinterpret_cast<const v4f *>(a.coef + src);
-                    dst[k] = q * 4;
+                    const int p = min(pb + 2 * k + sub, planes - 1);
+                    const size_t plane_off = (size_t)((m0 - 1 + p) & mask) * n * n;
+                    c[k][0] = *reinterpret_cast<const v4f *>(row0 + plane_off);
+                    c[k][1] = *reinterpret_cast<const v4f *>(row1 + plane_off);
+                    c[k][2] = *reinterpret_cast<const v4f *>(row2 + plane_off);
                 }
 #pragma unroll
-                for (int k = 0; k < kBatch; ++k) *reinterpret_cast<v4f *>(table + dst[k]) = c[k];
+                for (int k = 0; k < kBatch; ++k) {
+                    const int p = min(pb + 2 * k + sub, planes - 1);
+                    v4f yv;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        yv[q] = __builtin_fmaf(wy2, c[k][2][q], __builtin_fmaf(wy1, c[k][1][q], wy0 * c[k][0][q]));
+                    *reinterpret_cast<v4f *>(ytab + p * kCols + 4 * quad) = yv;
+                }
             }
         }
-        // y-collapse of a plane: columns lane and 64 + (lane & 31) of this wave's three rows
-        const float *const ca = table + d * kRowFloats + lane, *const cb = table + d * kRowFloats + 64 + (lane & 31);
-        auto collapse = [&](int kz, float (&yv)[2]) {
-            const int s = min(kz - (m0 - 1), planes - 1) * (kCW * kRowFloats); // past the item's planes: values no stored plane uses
-            yv[0] = __builtin_fmaf(wy2, ca[s + 2 * kRowFloats], __builtin_fmaf(wy1, ca[s + kRowFloats], wy0 * ca[s]));
-            yv[1] = __builtin_fmaf(wy2, cb[s + 2 * kRowFloats], __builtin_fmaf(wy1, cb[s + kRowFloats], wy0 * cb[s]));
+        // ---- z table of the item; 3 pad entries repeat the last plane (the march runs ahead) ---------
+        for (int i = lane; i < zn + 3; i += 64) {
+            int m;
+            float w0, w1, w2;
+            wn::bspline(coord(g.z0 + zb + min(i, zn - 1), den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), m, w0, w1, w2);
+            *reinterpret_cast<v4f *>(ztab + 4 * i) = v4f{__int_as_float(m), w0 * g.out_scale, w1 * g.out_scale, w2 * g.out_scale};
+        }
+        // lane = coefficient column from here on: column lane, and column 64 + (lane & 31)
+        const float *const ya = ytab + lane, *const yb = ytab + 64 + (lane & 31);
+        auto load_y = [&](int p, float (&yv)[2]) {
+            const int pc = min(p, planes - 1) * kCols; // past the item's planes: values no stored plane uses
+            yv[0] = ya[pc];
+            yv[1] = yb[pc];
         };
-        lds_barrier(); // set-up: z table and coefficient table written
         int cur_mid = m0;
         float Y0[2], Y1[2], Y2[2], Y3[2]; // planes cur_mid-1 .. cur_mid+2 (Y3: the prefetched next one)
-        collapse(m0 - 1, Y0);
-        collapse(m0, Y1);
-        collapse(m0 + 1, Y2);
-        collapse(m0 + 2, Y3);
+        load_y(0, Y0);
+        load_y(1, Y1);
+        load_y(2, Y2);
+        load_y(3, Y3);
 
         // R values (columns lane, 64 + (lane & 31)) of a plane; `e` = its table entry {mid, wz0, wz1, wz2}
         auto r_values = [&](const v4f e, float &ra, float &rb) {
@@ -272,7 +257,7 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
                 Y0[0] = Y1[0]; Y0[1] = Y1[1];
                 Y1[0] = Y2[0]; Y1[1] = Y2[1];
                 Y2[0] = Y3[0]; Y2[1] = Y3[1];
-                collapse(m + 2, Y3);
+                load_y(m - m0 + 3, Y3);
             }
             ra = __builtin_fmaf(e.w, Y2[0], __builtin_fmaf(e.z, Y1[0], e.y * Y0[0]));
             rb = __builtin_fmaf(e.w, Y2[1], __builtin_fmaf(e.z, Y1[1], e.y * Y0[1]));
@@ -296,7 +281,6 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
                          : "memory");
         };
 
-        stamp();
         write_r(0, zt[0]);
         write_r(1, zt[1]);
         float *const park = stage + wave * 256 + lane * 4;
@@ -334,7 +318,6 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
         }
         if (z < zn) { step(z, wa, wb, ea, eb, 1); ++z; }
         lds_barrier(); // hands over the last row
-        stamp();
         for (; z <= a.chunk_len; ++z) lds_barrier(); // a short last chunk, and the barrier closing the round
     }
 }
@@ -358,26 +341,23 @@ int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_
     const double pmax = step * imax + 1.0;
     if (pmax > 1.0e6) return WN_OK;
     const double slack = pmax * 4.8e-7; // fp32 rounding of a coordinate, in planes
-    // 4 consecutive samples (x quad of a lane, y rows of an item) span <= 2 mids, and a plane change
-    // advances the mid by exactly 1
-    if (step < 0.18) return WN_OK; // finer lattices: the brick kernel is as fast or faster
-    if (3.0 * step + slack > 1.0) return WN_OK;
-    if (255.0 * step + slack + 7.0 > (double)kCols) return WN_OK; // columns of a block (+3 of alignment)
-    const long long groups = (long long)(g.nx / 256) * ((g.ny + kCW - 1) / kCW);
-    if (groups > 0x3fffffffLL) return WN_OK;
+    if (step < 0.18) return WN_OK;                           // finer lattices: the brick kernel is as fast or faster
+    if (3.0 * step + slack > 1.0) return WN_OK;              // 4 consecutive samples span <= 2 mids
+    if (255.0 * step + slack + 7.0 > (double)kCols) return WN_OK; // columns of a segment (+3 of alignment)
+    const long long segs = (long long)(g.nx / 256) * g.ny;
+    if (segs > 0x3fffffffLL) return WN_OK;
 
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         cus = prop.multiProcessorCount;
-    // planes per item: the z table must fit, and every workgroup slot of the chip (two per CU) should get an item
-    int nchunks = (g.nz + kMaxChunk - 1) / kMaxChunk;
+    // planes per item: the item's coefficient planes must fit the LDS table, and every compute wave of the
+    // chip should have an item
     int chunk_max = kMaxChunk;
     if (step > 0.0) chunk_max = (int)std::min<double>(kMaxChunk, std::floor((kPlanes - 5 - slack) / step) + 1.0);
     if (chunk_max < 8) return WN_OK;
-    nchunks = (g.nz + chunk_max - 1) / chunk_max;
-    const long long wgs = 2LL * cus;
-    while (groups * nchunks < wgs && (g.nz + 2 * nchunks - 1) / (2 * nchunks) >= 32) nchunks *= 2;
+    int nchunks = (g.nz + chunk_max - 1) / chunk_max;
+    while (segs * nchunks < 8LL * cus && (g.nz + 2 * nchunks - 1) / (2 * nchunks) >= 32) nchunks *= 2;
     StripArgs a{};
     a.coef = tile->dev;
     a.out = out_dev;
@@ -386,9 +366,9 @@ int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_
     a.g = g;
     a.inv_den = ((g.den & (g.den - 1)) == 0) ? 1.0f / (float)g.den : 0.0f;
     a.segs_per_row = g.nx / 256;
-    a.total_groups = (int)groups;
+    a.total_segs = (int)segs;
     a.chunk_len = (g.nz + nchunks - 1) / nchunks;
-    const long long items = groups * ((g.nz + a.chunk_len - 1) / a.chunk_len);
+    const long long items = segs * ((g.nz + a.chunk_len - 1) / a.chunk_len);
     if (items > 0x3fffffffLL) return WN_OK;
     a.total_items = (int)items;
     static int big_lds_device = -1; // dynamic LDS beyond 64 KiB needs a per-device opt-in for this kernel
@@ -397,27 +377,9 @@ int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         big_lds_device = dev;
     }
-    const int blocks = (int)std::min<long long>(items, wgs);
-#ifdef WN_STRIP_STAMPS
-    static unsigned long long *dbg = nullptr;
-    static int dbg_calls = 0;
-    if (!dbg) { (void)hipMalloc(&dbg, 16 * 16 * 8); (void)hipMemset(dbg, 0, 16 * 16 * 8); }
-    a.stamps = dbg;
-#endif
+    const int blocks = (int)std::min<long long>((items + kCW - 1) / kCW, (long long)kWgPerCu * cus);
     hipLaunchKernelGGL(grid3d_strip_kernel, dim3(blocks), dim3(64 * (kCW + kSW)), kLdsBytes, stream, a);
     WN_LAUNCH_CHECK("grid3d_strip_kernel");
-#ifdef WN_STRIP_STAMPS
-    if (++dbg_calls == 5) {
-        unsigned long long h[256];
-        (void)hipDeviceSynchronize();
-        (void)hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost);
-        for (int b = 0; b < 8; ++b) {
-            fprintf(stderr, "stamps wg %d:", b * 65);
-            for (int i = 1; i < 8; ++i) fprintf(stderr, " %.2f", (double)(h[b * 16 + i] - h[b * 16]) / 100.0);
-            fprintf(stderr, " us\n");
-        }
-    }
-#endif
     *launched = true;
     return WN_OK;
 }
