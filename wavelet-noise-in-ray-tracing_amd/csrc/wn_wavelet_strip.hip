@@ -30,9 +30,9 @@
 //   * The store wave paired with the compute wave moves each parked row to memory.  The barrier of
 //     step z sits in the middle of step z+1 and shares a statement with that step's R write, with a
 //     counted lgkmcnt: no LDS latency is waited out at the barrier.
-//   * The two workgroups of a CU swap wave priority between their two items (s_setprio): the
-//     arbiter otherwise favours the older workgroup all the way, which then finishes 15-20 us early
-//     and leaves the CU half empty (111 -> 104 us at 512^3).
+//   * The two workgroups of a CU swap wave priority every 64 planes (s_setprio): the arbiter
+//     otherwise favours the older workgroup all the way, which then finishes 15-20 us early and
+//     leaves the CU half empty (worth 5-8 % at 512^3).
 // Per-axis mids / weights are computed exactly as the reference does (WaveletNoise.cpp:194-200);
 // only the order of the final sums differs (tolerance 1e-5, like the brick kernel).
 #include "wn_internal.hpp"
@@ -97,10 +97,11 @@ __device__ __forceinline__ unsigned lds_address(const float *p)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // The first half of the grid (dispatched first, one workgroup per CU) and the second half share the CUs; they
-// take turns at the higher wave priority, item by item.
-__device__ __forceinline__ void set_round_priority(int round)
+// take turns at the higher wave priority, kPrioPeriod planes at a time.
+constexpr int kPrioPeriod = 64;
+__device__ __forceinline__ void set_turn_priority(int turn)
 {
-    if (((blockIdx.x >= gridDim.x / 2) ^ (round & 1)) != 0) __builtin_amdgcn_s_setprio(1);
+    if (((blockIdx.x >= gridDim.x / 2) ^ (turn & 1)) != 0) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
 }
 
@@ -126,7 +127,6 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
         // ---- store waves: no arithmetic, no loads --------------------------------------------------------
         const int c = wave - kCW;
         for (int round = 0; round < rounds; ++round) {
-            set_round_priority(round);
             const int item = round * gridDim.x + blockIdx.x;
             const int chunk = item / a.total_groups, grp = item - chunk * a.total_groups;
             const int yg = grp / a.segs_per_row, xs = grp - yg * a.segs_per_row;
@@ -137,6 +137,8 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
             const float *src = stage + c * 256 + lane * 4;
             lds_barrier(); // set-up
             for (int t = 0; t < a.chunk_len; ++t) {
+                const int gt = round * a.chunk_len + t; // planes since the kernel started
+                if ((gt & (kPrioPeriod - 1)) == 0) set_turn_priority(gt / kPrioPeriod);
                 lds_barrier();
                 if (t < zn) {
                     *reinterpret_cast<v4f *>(dst) = *reinterpret_cast<const v4f *>(src + (t & 1) * (kCW * 256));
@@ -161,7 +163,6 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
     const float den = (float)g.den;
     const int n = a.n, mask = a.nmask;
     for (int round = 0; round < rounds; ++round) {
-        set_round_priority(round);
         const int item = round * gridDim.x + blockIdx.x;
         if (item >= a.total_items) { // same barriers, no work
             for (int t = 0; t <= a.chunk_len + 1; ++t) lds_barrier();
@@ -329,6 +330,8 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
         }
         int z = 0;
         for (; z + 1 < zn; z += 2) {
+            const int gz = round * a.chunk_len + z; // planes since the kernel started; two per trip
+            if ((gz & (kPrioPeriod - 1)) <= 1) set_turn_priority(gz / kPrioPeriod);
             step(z, wa, wb, ea, eb, 1);
             step(z + 1, wb, wa, eb, ea, 0);
         }
