@@ -70,8 +70,9 @@ struct StripArgs {
     float inv_den;    // 1/den when den is a power of two (exact), else 0
     int segs_per_row; // nx / 256
     int total_groups; // segs_per_row * ceil(ny / 4): groups of four rows of one column block
-    int chunk_len;    // planes per item
-    int total_items;  // total_groups * number of z chunks
+    int range_len;    // planes of one owner range: a workgroup takes (group, range) pairs ...
+    int owners;       // ... total_groups * number of ranges of them
+    int chunk_len;    // and walks a range in items of at most this many planes
 #ifdef WN_STRIP_STAMPS
     unsigned long long *stamps; // debug build: phase time stamps of a few workgroups
 #endif
@@ -118,34 +119,36 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
     float *const rrows = stage + kStageFloats;
     float *const ztab = rrows + kCW * 2 * kRRow; // per plane of the item {mid_z, wz0, wz1, wz2}, + 3 pad entries
     const size_t plane_stride = (size_t)g.ny * g.nx;
-    // Every wave of the workgroup passes the same barriers.  Per round (= item): one after the item's
-    // set-up, one per plane of a full chunk, one closing the round.  Plane t: compute wave c parks its row
-    // in stage[t&1][c]; after the barrier store wave c moves it to memory while the compute waves are on t+1.
-    const int rounds = (a.total_items + gridDim.x - 1) / gridDim.x;
+    // Work: owner ranges (group of four rows, range of planes), walked in items.
+    // Every wave of the workgroup passes the same barriers.  Per item: one after its set-up, one per plane,
+    // one closing it.  Plane t: compute wave c parks its row in stage[t&1][c]; after the barrier store wave c
+    // moves it to memory while the compute waves are on t+1.
+    int gt = 0; // planes this workgroup has done: the priority turns follow it
 
     if (wave >= kCW) {
         // ---- store waves: no arithmetic, no loads --------------------------------------------------------
         const int c = wave - kCW;
-        for (int round = 0; round < rounds; ++round) {
-            const int item = round * gridDim.x + blockIdx.x;
-            const int chunk = item / a.total_groups, grp = item - chunk * a.total_groups;
+        for (int owner = blockIdx.x; owner < a.owners; owner += gridDim.x) {
+            const int range = owner / a.total_groups, grp = owner - range * a.total_groups;
             const int yg = grp / a.segs_per_row, xs = grp - yg * a.segs_per_row;
-            const int zb = chunk * a.chunk_len;
+            const int z_lo = range * a.range_len, z_hi = min(g.nz, z_lo + a.range_len);
             const int row = yg * kCW + c; // the last group of a lattice with ny % 4 != 0 has rows past the end: computed, not stored
-            const int zn = (item < a.total_items && row < g.ny) ? min(a.chunk_len, g.nz - zb) : 0;
-            float *dst = a.out + ((size_t)zb * plane_stride + (size_t)row * g.nx + xs * 256 + lane * 4);
+            float *dst = a.out + ((size_t)z_lo * plane_stride + (size_t)row * g.nx + xs * 256 + lane * 4);
             const float *src = stage + c * 256 + lane * 4;
-            lds_barrier(); // set-up
-            for (int t = 0; t < a.chunk_len; ++t) {
-                const int gt = round * a.chunk_len + t; // planes since the kernel started
-                if ((gt & (kPrioPeriod - 1)) == 0) set_turn_priority(gt / kPrioPeriod);
-                lds_barrier();
-                if (t < zn) {
-                    *reinterpret_cast<v4f *>(dst) = *reinterpret_cast<const v4f *>(src + (t & 1) * (kCW * 256));
-                    dst += plane_stride;
+            for (int zb = z_lo; zb < z_hi;) {
+                const int zn = min(a.chunk_len, z_hi - zb);
+                lds_barrier(); // set-up
+                for (int t = 0; t < zn; ++t, ++gt) {
+                    if ((gt & (kPrioPeriod - 1)) == 0) set_turn_priority(gt / kPrioPeriod);
+                    lds_barrier();
+                    if (row < g.ny) {
+                        *reinterpret_cast<v4f *>(dst) = *reinterpret_cast<const v4f *>(src + (t & 1) * (kCW * 256));
+                        dst += plane_stride;
+                    }
                 }
+                lds_barrier(); // item closed: stage, tables may be rewritten
+                zb += zn;
             }
-            lds_barrier(); // round closed: stage and z table may be rewritten
         }
         return;
     }
@@ -162,25 +165,12 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
     const v4f *const zt = reinterpret_cast<const v4f *>(ztab);
     const float den = (float)g.den;
     const int n = a.n, mask = a.nmask;
-    for (int round = 0; round < rounds; ++round) {
-        const int item = round * gridDim.x + blockIdx.x;
-        if (item >= a.total_items) { // same barriers, no work
-            for (int t = 0; t <= a.chunk_len + 1; ++t) lds_barrier();
-            continue;
-        }
-        const int chunk = item / a.total_groups, grp = item - chunk * a.total_groups;
+    for (int owner = blockIdx.x; owner < a.owners; owner += gridDim.x) {
+        const int range = owner / a.total_groups, grp = owner - range * a.total_groups;
         const int yg = grp / a.segs_per_row, xs = grp - yg * a.segs_per_row;
-        const int zb = chunk * a.chunk_len, zn = min(a.chunk_len, g.nz - zb);
+        const int z_lo = range * a.range_len, z_hi = min(g.nz, z_lo + a.range_len);
         const int y = yg * kCW + wave;
         const int x_first = xs * 256, x0 = x_first + lane * 4;
-
-        // ---- z table of the item (the four compute waves together); 3 pad entries repeat the last plane
-        for (int i = tid; i < zn + 3; i += 64 * kCW) {
-            int m;
-            float w0, w1, w2;
-            wn::bspline(coord(g.z0 + zb + min(i, zn - 1), den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), m, w0, w1, w2);
-            *reinterpret_cast<v4f *>(ztab + 4 * i) = v4f{__int_as_float(m), w0 * g.out_scale, w1 * g.out_scale, w2 * g.out_scale};
-        }
         // ---- x: this lane's four samples -> 16 window weights, window start as a column index ------
         int mx_first;
         {
@@ -209,136 +199,152 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
         }
         // ---- y: the item's rows y0..y0+3 have mids my_first or my_first+1 (host: 3 steps span < 1), so the
         // four tile rows my_first-1 .. my_first+2 serve all of them; this wave's three start at row d.
-        int my_first, my_v, m0;
+        int my_first, my_v;
         float wy0, wy1, wy2;
         {
             float t0, t1, t2;
             wn::bspline(coord(yg * kCW, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), my_first, t0, t1, t2);
-            wn::bspline(coord(g.z0 + zb, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), m0, t0, t1, t2);
         }
         wn::bspline(coord(y, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), my_v, wy0, wy1, wy2);
         my_first = __builtin_amdgcn_readfirstlane(my_first);
-        m0 = __builtin_amdgcn_readfirstlane(m0);
         const int d = min(max(__builtin_amdgcn_readfirstlane(my_v) - my_first, 0), 1);
 
-        // ---- coefficient table of the item: planes m0-1 .. m_last+1, tile rows my_first-1 .. my_first+2,
-        // columns ix0 .. ix0+95, filled by the four compute waves together (16 bytes per lane and load, aligned:
-        // no wrap inside a quad)
-        int m_last;
-        {
-            float t0, t1, t2;
-            wn::bspline(coord(g.z0 + zb + zn - 1, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), m_last, t0, t1, t2);
-            m_last = __builtin_amdgcn_readfirstlane(m_last);
-        }
-        const int planes = min(m_last - m0 + 3, kPlanes); // the host guarantees the bound
-        {
-            constexpr int kBatch = 8, kQuads = kCols / 4;
-            const int total = planes * kCW * kQuads; // (plane, tile row, quad) triples
-            for (int q0 = 0; q0 < total; q0 += kBatch * 64 * kCW) {
-                v4f c[kBatch];
-                int dst[kBatch];
+        for (int zb = z_lo; zb < z_hi;) { // the items of the range
+            const int zn = min(a.chunk_len, z_hi - zb);
+            // ---- z table of the item (the four compute waves together); 3 pad entries repeat the last plane
+            for (int i = tid; i < zn + 3; i += 64 * kCW) {
+                int m;
+                float w0, w1, w2;
+                wn::bspline(coord(g.z0 + zb + min(i, zn - 1), den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), m, w0, w1, w2);
+                *reinterpret_cast<v4f *>(ztab + 4 * i) = v4f{__int_as_float(m), w0 * g.out_scale, w1 * g.out_scale, w2 * g.out_scale};
+            }
+            int m0;
+            {
+                float t0, t1, t2;
+                wn::bspline(coord(g.z0 + zb, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), m0, t0, t1, t2);
+                m0 = __builtin_amdgcn_readfirstlane(m0);
+            }
+
+            // ---- coefficient table of the item: planes m0-1 .. m_last+1, tile rows my_first-1 .. my_first+2,
+            // columns ix0 .. ix0+95, filled by the four compute waves together (16 bytes per lane and load, aligned:
+            // no wrap inside a quad)
+            int m_last;
+            {
+                float t0, t1, t2;
+                wn::bspline(coord(g.z0 + zb + zn - 1, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), m_last, t0, t1, t2);
+                m_last = __builtin_amdgcn_readfirstlane(m_last);
+            }
+            const int planes = min(m_last - m0 + 3, kPlanes); // the host guarantees the bound
+            {
+                constexpr int kBatch = 8, kQuads = kCols / 4;
+                const int total = planes * kCW * kQuads; // (plane, tile row, quad) triples
+                for (int q0 = 0; q0 < total; q0 += kBatch * 64 * kCW) {
+                    v4f c[kBatch];
+                    int dst[kBatch];
 #pragma unroll
-                for (int k = 0; k < kBatch; ++k) {
-                    const int q = min(q0 + k * 64 * kCW + tid, total - 1); // past the end: repeat the last triple
-                    const int p = q / (kCW * kQuads), rq = q - p * (kCW * kQuads), row = rq / kQuads, quad = rq - row * kQuads;
-                    const size_t src = (size_t)((m0 - 1 + p) & mask) * n * n + (size_t)((my_first - 1 + row) & mask) * n
-                                       + (size_t)((ix0 + 4 * quad) & mask);
-                    c[k] = *reinterpret_cast<const v4f *>(a.coef + src);
-                    dst[k] = q * 4;
+                    for (int k = 0; k < kBatch; ++k) {
+                        const int q = min(q0 + k * 64 * kCW + tid, total - 1); // past the end: repeat the last triple
+                        const int p = q / (kCW * kQuads), rq = q - p * (kCW * kQuads), row = rq / kQuads, quad = rq - row * kQuads;
+                        const size_t src = (size_t)((m0 - 1 + p) & mask) * n * n + (size_t)((my_first - 1 + row) & mask) * n
+                                           + (size_t)((ix0 + 4 * quad) & mask);
+                        c[k] = *reinterpret_cast<const v4f *>(a.coef + src);
+                        dst[k] = q * 4;
+                    }
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) *reinterpret_cast<v4f *>(table + dst[k]) = c[k];
                 }
-#pragma unroll
-                for (int k = 0; k < kBatch; ++k) *reinterpret_cast<v4f *>(table + dst[k]) = c[k];
             }
-        }
-        // y-collapse of a plane: columns lane and 64 + (lane & 31) of this wave's three rows
-        const float *const ca = table + d * kRowFloats + lane, *const cb = table + d * kRowFloats + 64 + (lane & 31);
-        auto collapse = [&](int kz, float (&yv)[2]) {
-            const int s = min(kz - (m0 - 1), planes - 1) * (kCW * kRowFloats); // past the item's planes: values no stored plane uses
-            yv[0] = __builtin_fmaf(wy2, ca[s + 2 * kRowFloats], __builtin_fmaf(wy1, ca[s + kRowFloats], wy0 * ca[s]));
-            yv[1] = __builtin_fmaf(wy2, cb[s + 2 * kRowFloats], __builtin_fmaf(wy1, cb[s + kRowFloats], wy0 * cb[s]));
-        };
-        lds_barrier(); // set-up: z table and coefficient table written
-        int cur_mid = m0;
-        float Y0[2], Y1[2], Y2[2], Y3[2]; // planes cur_mid-1 .. cur_mid+2 (Y3: the prefetched next one)
-        collapse(m0 - 1, Y0);
-        collapse(m0, Y1);
-        collapse(m0 + 1, Y2);
-        collapse(m0 + 2, Y3);
+            // y-collapse of a plane: columns lane and 64 + (lane & 31) of this wave's three rows
+            const float *const ca = table + d * kRowFloats + lane, *const cb = table + d * kRowFloats + 64 + (lane & 31);
+            auto collapse = [&](int kz, float (&yv)[2]) {
+                const int s = min(kz - (m0 - 1), planes - 1) * (kCW * kRowFloats); // past the item's planes: values no stored plane uses
+                yv[0] = __builtin_fmaf(wy2, ca[s + 2 * kRowFloats], __builtin_fmaf(wy1, ca[s + kRowFloats], wy0 * ca[s]));
+                yv[1] = __builtin_fmaf(wy2, cb[s + 2 * kRowFloats], __builtin_fmaf(wy1, cb[s + kRowFloats], wy0 * cb[s]));
+            };
+            lds_barrier(); // set-up: z table and coefficient table written
+            int cur_mid = m0;
+            float Y0[2], Y1[2], Y2[2], Y3[2]; // planes cur_mid-1 .. cur_mid+2 (Y3: the prefetched next one)
+            collapse(m0 - 1, Y0);
+            collapse(m0, Y1);
+            collapse(m0 + 1, Y2);
+            collapse(m0 + 2, Y3);
 
-        // R values (columns lane, 64 + (lane & 31)) of a plane; `e` = its table entry {mid, wz0, wz1, wz2}
-        auto r_values = [&](const v4f e, float &ra, float &rb) {
-            const int m = __builtin_amdgcn_readfirstlane(__float_as_int(e.x));
-            if (__builtin_expect(m != cur_mid, 0)) { // entered the next coefficient plane (mids advance by exactly 1)
-                cur_mid = m;
-                Y0[0] = Y1[0]; Y0[1] = Y1[1];
-                Y1[0] = Y2[0]; Y1[1] = Y2[1];
-                Y2[0] = Y3[0]; Y2[1] = Y3[1];
-                collapse(m + 2, Y3);
-            }
-            ra = __builtin_fmaf(e.w, Y2[0], __builtin_fmaf(e.z, Y1[0], e.y * Y0[0]));
-            rb = __builtin_fmaf(e.w, Y2[1], __builtin_fmaf(e.z, Y1[1], e.y * Y0[1]));
-        };
-        float *const r_a = rb0 + lane, *const r_b = rb0 + 64 + (lane & 31); // + kRRow for the other buffer
-        auto write_r = [&](int buf, const v4f e) {
-            float ra, rb;
-            r_values(e, ra, rb);
-            r_a[buf * kRRow] = ra;
-            r_b[buf * kRRow] = rb;
-        };
-        // The same, and the workgroup barrier that hands over the output row parked a step ago, in one
-        // statement: the counted wait leaves only these R writes outstanding (LDS operations of a wave
-        // complete in issue order), so the barrier does not wait out an LDS write latency.  hipcc does not
-        // count the hidden writes; unknown operations can only make its own waits stricter.
-        auto write_r_handover = [&](int buf, const v4f e) {
-            float ra, rb;
-            r_values(e, ra, rb);
-            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %2, %3\n\ts_waitcnt lgkmcnt(2)\n\ts_barrier"
-                         :: "v"(lds_address(r_a + buf * kRRow)), "v"(ra), "v"(lds_address(r_b + buf * kRRow)), "v"(rb)
-                         : "memory");
-        };
+            // R values (columns lane, 64 + (lane & 31)) of a plane; `e` = its table entry {mid, wz0, wz1, wz2}
+            auto r_values = [&](const v4f e, float &ra, float &rb) {
+                const int m = __builtin_amdgcn_readfirstlane(__float_as_int(e.x));
+                if (__builtin_expect(m != cur_mid, 0)) { // entered the next coefficient plane (mids advance by exactly 1)
+                    cur_mid = m;
+                    Y0[0] = Y1[0]; Y0[1] = Y1[1];
+                    Y1[0] = Y2[0]; Y1[1] = Y2[1];
+                    Y2[0] = Y3[0]; Y2[1] = Y3[1];
+                    collapse(m + 2, Y3);
+                }
+                ra = __builtin_fmaf(e.w, Y2[0], __builtin_fmaf(e.z, Y1[0], e.y * Y0[0]));
+                rb = __builtin_fmaf(e.w, Y2[1], __builtin_fmaf(e.z, Y1[1], e.y * Y0[1]));
+            };
+            float *const r_a = rb0 + lane, *const r_b = rb0 + 64 + (lane & 31); // + kRRow for the other buffer
+            auto write_r = [&](int buf, const v4f e) {
+                float ra, rb;
+                r_values(e, ra, rb);
+                r_a[buf * kRRow] = ra;
+                r_b[buf * kRRow] = rb;
+            };
+            // The same, and the workgroup barrier that hands over the output row parked a step ago, in one
+            // statement: the counted wait leaves only these R writes outstanding (LDS operations of a wave
+            // complete in issue order), so the barrier does not wait out an LDS write latency.  hipcc does not
+            // count the hidden writes; unknown operations can only make its own waits stricter.
+            auto write_r_handover = [&](int buf, const v4f e) {
+                float ra, rb;
+                r_values(e, ra, rb);
+                asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %2, %3\n\ts_waitcnt lgkmcnt(2)\n\ts_barrier"
+                             :: "v"(lds_address(r_a + buf * kRRow)), "v"(ra), "v"(lds_address(r_b + buf * kRRow)), "v"(rb)
+                             : "memory");
+            };
 
-        stamp();
-        write_r(0, zt[0]);
-        write_r(1, zt[1]);
-        float *const park = stage + wave * 256 + lane * 4;
-        // One plane.  Issued first: the reads for LATER steps -- the window of R(z+1), written a step
-        // ago into buffer `rd`, and the table entry of plane z+3.  Then R(z+2) from `e_use` into the
-        // other buffer (with the hand-over of row z-1), then this plane's 16 window FMAs on `cur` (read a
-        // step ago) and the parking of its row.  The two register sets alternate between the two halves
-        // of the unrolled loop: no value is waited for in the step that requested it.
-        auto step = [&](int z, const float (&cur)[4], float (&nxt)[4], const v4f &e_use, v4f &e_load, int rd) {
-            const float *r = rb0 + rd * kRRow + wbase;
-            nxt[0] = r[0]; nxt[1] = r[1]; nxt[2] = r[2]; nxt[3] = r[3];
-            e_load = zt[z + 3];
-            if (z != 0) write_r_handover(rd ^ 1, e_use);
-            else write_r(rd ^ 1, e_use);
-            float o[4];
+            stamp();
+            write_r(0, zt[0]);
+            write_r(1, zt[1]);
+            float *const park = stage + wave * 256 + lane * 4;
+            // One plane.  Issued first: the reads for LATER steps -- the window of R(z+1), written a step
+            // ago into buffer `rd`, and the table entry of plane z+3.  Then R(z+2) from `e_use` into the
+            // other buffer (with the hand-over of row z-1), then this plane's 16 window FMAs on `cur` (read a
+            // step ago) and the parking of its row.  The two register sets alternate between the two halves
+            // of the unrolled loop: no value is waited for in the step that requested it.
+            auto step = [&](int z, const float (&cur)[4], float (&nxt)[4], const v4f &e_use, v4f &e_load, int rd) {
+                const float *r = rb0 + rd * kRRow + wbase;
+                nxt[0] = r[0]; nxt[1] = r[1]; nxt[2] = r[2]; nxt[3] = r[3];
+                e_load = zt[z + 3];
+                if (z != 0) write_r_handover(rd ^ 1, e_use);
+                else write_r(rd ^ 1, e_use);
+                float o[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float t = ww[q][0] * cur[0];
-                t = __builtin_fmaf(ww[q][1], cur[1], t);
-                t = __builtin_fmaf(ww[q][2], cur[2], t);
-                o[q] = __builtin_fmaf(ww[q][3], cur[3], t);
+                for (int q = 0; q < 4; ++q) {
+                    float t = ww[q][0] * cur[0];
+                    t = __builtin_fmaf(ww[q][1], cur[1], t);
+                    t = __builtin_fmaf(ww[q][2], cur[2], t);
+                    o[q] = __builtin_fmaf(ww[q][3], cur[3], t);
+                }
+                *reinterpret_cast<v4f *>(park + (z & 1) * (kCW * 256)) = v4f{o[0], o[1], o[2], o[3]};
+            };
+            float wa[4], wb[4];
+            v4f ea = zt[2], eb;
+            {
+                const float *r = rb0 + wbase;
+                wa[0] = r[0]; wa[1] = r[1]; wa[2] = r[2]; wa[3] = r[3];
             }
-            *reinterpret_cast<v4f *>(park + (z & 1) * (kCW * 256)) = v4f{o[0], o[1], o[2], o[3]};
-        };
-        float wa[4], wb[4];
-        v4f ea = zt[2], eb;
-        {
-            const float *r = rb0 + wbase;
-            wa[0] = r[0]; wa[1] = r[1]; wa[2] = r[2]; wa[3] = r[3];
+            int z = 0;
+            for (; z + 1 < zn; z += 2) {
+                if (((gt + z) & (kPrioPeriod - 1)) <= 1) set_turn_priority((gt + z) / kPrioPeriod); // two planes per trip
+                step(z, wa, wb, ea, eb, 1);
+                step(z + 1, wb, wa, eb, ea, 0);
+            }
+            if (z < zn) step(z, wa, wb, ea, eb, 1);
+            lds_barrier(); // hands over the last row
+            stamp();
+            lds_barrier(); // item closed: stage, tables may be rewritten
+            gt += zn;
+            zb += zn;
         }
-        int z = 0;
-        for (; z + 1 < zn; z += 2) {
-            const int gz = round * a.chunk_len + z; // planes since the kernel started; two per trip
-            if ((gz & (kPrioPeriod - 1)) <= 1) set_turn_priority(gz / kPrioPeriod);
-            step(z, wa, wb, ea, eb, 1);
-            step(z + 1, wb, wa, eb, ea, 0);
-        }
-        if (z < zn) { step(z, wa, wb, ea, eb, 1); ++z; }
-        lds_barrier(); // hands over the last row
-        stamp();
-        for (; z <= a.chunk_len; ++z) lds_barrier(); // a short last chunk, and the barrier closing the round
     }
 }
 
@@ -373,14 +379,14 @@ int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         cus = prop.multiProcessorCount;
-    // planes per item: the z table must fit, and every workgroup slot of the chip (two per CU) should get an item
-    int nchunks = (g.nz + kMaxChunk - 1) / kMaxChunk;
+    // items: the planes an item touches must fit its LDS table
     int chunk_max = kMaxChunk;
     if (step > 0.0) chunk_max = (int)std::min<double>(kMaxChunk, std::floor((kPlanes - 5 - slack) / step) + 1.0);
     if (chunk_max < 8) return WN_OK;
-    nchunks = (g.nz + chunk_max - 1) / chunk_max;
+    // owner ranges: every workgroup slot of the chip (two per CU) should get one, as long as a range keeps >= 32 planes
     const long long wgs = 2LL * cus;
-    while (groups * nchunks < wgs && (g.nz + 2 * nchunks - 1) / (2 * nchunks) >= 32) nchunks *= 2;
+    int nranges = 1;
+    while (groups * nranges < wgs && (g.nz + 2 * nranges - 1) / (2 * nranges) >= 32) nranges *= 2;
     StripArgs a{};
     a.coef = tile->dev;
     a.out = out_dev;
@@ -390,17 +396,20 @@ int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_
     a.inv_den = ((g.den & (g.den - 1)) == 0) ? 1.0f / (float)g.den : 0.0f;
     a.segs_per_row = g.nx / 256;
     a.total_groups = (int)groups;
-    a.chunk_len = (g.nz + nchunks - 1) / nchunks;
-    const long long items = groups * ((g.nz + a.chunk_len - 1) / a.chunk_len);
-    if (items > 0x3fffffffLL) return WN_OK;
-    a.total_items = (int)items;
+    a.range_len = (g.nz + nranges - 1) / nranges;
+    const long long owners = groups * ((g.nz + a.range_len - 1) / a.range_len);
+    if (owners > 0x3fffffffLL) return WN_OK;
+    a.owners = (int)owners;
+    // a range is walked in equal items of at most chunk_max planes
+    const int per_range = (a.range_len + chunk_max - 1) / chunk_max;
+    a.chunk_len = (a.range_len + per_range - 1) / per_range;
     static int big_lds_device = -1; // dynamic LDS beyond 64 KiB needs a per-device opt-in for this kernel
     if (big_lds_device != dev) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&grid3d_strip_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         big_lds_device = dev;
     }
-    const int blocks = (int)std::min<long long>(items, wgs);
+    const int blocks = (int)std::min<long long>(owners, wgs);
 #ifdef WN_STRIP_STAMPS
     static unsigned long long *dbg = nullptr;
     static int dbg_calls = 0;
