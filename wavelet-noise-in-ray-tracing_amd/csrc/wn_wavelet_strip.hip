@@ -54,7 +54,7 @@ constexpr int kSW = kCW;        // store waves per workgroup (one per compute wa
 constexpr int kCols = 96;       // coefficient columns an item may touch (host: 255*step + 7 <= 96)
 constexpr int kPlanes = 38;     // coefficient planes an item may touch (host: (chunk_len-1)*step + 5 <= 38)
 constexpr int kRowFloats = 96;  // table row = kCols
-constexpr int kMaxChunk = 128;  // planes per item
+constexpr int kMaxChunk = 256;  // planes per item (z table: 16 B per plane)
 constexpr int kRRow = 100;      // one R row (96 columns + pad)
 constexpr int kTableFloats = kPlanes * kCW * kRowFloats; // the item's coefficient table [plane][tile row 0..3][96]
 constexpr int kStageFloats = 2 * kCW * 256; // two steps x one 1-KiB output row per compute wave
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
         }
         const int ix0 = (mx_first - 1) & ~3; // coefficient column of table/R column 0, aligned for 16-byte loads
         float ww[4][4];
-        int wbase;
+        int wbase, nquads;
         {
             int m[4];
             float w[4][3];
@@ -188,6 +188,8 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
             for (int q = 0; q < 4; ++q)
                 wn::bspline(coord(x0 + q, den, a.inv_den, g.base_range, g.octave_scale, g.post_scale), m[q], w[q][0], w[q][1], w[q][2]);
             wbase = min(m[0] - 1 - ix0, kCols - 4); // the host guarantees m[0] + 2 - ix0 < kCols
+            // column quads the block touches: lane 63 holds the last window
+            nquads = min(__builtin_amdgcn_readlane(wbase, 63) / 4 + 2, kCols / 4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const bool up = m[q] != m[0]; // mid is m[0] or m[0]+1 (host guarantees step <= 1/3)
@@ -236,19 +238,19 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
             }
             const int planes = min(m_last - m0 + 3, kPlanes); // the host guarantees the bound
             {
-                constexpr int kBatch = 8, kQuads = kCols / 4;
-                const int total = planes * kCW * kQuads; // (plane, tile row, quad) triples
+                constexpr int kBatch = 8;
+                const int total = planes * kCW * nquads; // (plane, tile row, quad) triples
                 for (int q0 = 0; q0 < total; q0 += kBatch * 64 * kCW) {
                     v4f c[kBatch];
                     int dst[kBatch];
 #pragma unroll
                     for (int k = 0; k < kBatch; ++k) {
                         const int q = min(q0 + k * 64 * kCW + tid, total - 1); // past the end: repeat the last triple
-                        const int p = q / (kCW * kQuads), rq = q - p * (kCW * kQuads), row = rq / kQuads, quad = rq - row * kQuads;
+                        const int p = q / (kCW * nquads), rq = q - p * (kCW * nquads), row = rq / nquads, quad = rq - row * nquads;
                         const size_t src = (size_t)((m0 - 1 + p) & mask) * n * n + (size_t)((my_first - 1 + row) & mask) * n
                                            + (size_t)((ix0 + 4 * quad) & mask);
                         c[k] = *reinterpret_cast<const v4f *>(a.coef + src);
-                        dst[k] = q * 4;
+                        dst[k] = ((p * kCW + row) * (kCols / 4) + quad) * 4;
                     }
 #pragma unroll
                     for (int k = 0; k < kBatch; ++k) *reinterpret_cast<v4f *>(table + dst[k]) = c[k];
@@ -369,7 +371,7 @@ int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_
     const double slack = pmax * 4.8e-7; // fp32 rounding of a coordinate, in planes
     // 4 consecutive samples (x quad of a lane, y rows of an item) span <= 2 mids, and a plane change
     // advances the mid by exactly 1
-    if (step < 0.18) return WN_OK; // finer lattices: the brick kernel is as fast or faster
+    if (step < 0.18) return WN_OK; // finer lattices: the brick kernel is faster
     if (3.0 * step + slack > 1.0) return WN_OK;
     if (255.0 * step + slack + 7.0 > (double)kCols) return WN_OK; // columns of a block (+3 of alignment)
     const long long groups = (long long)(g.nx / 256) * ((g.ny + kCW - 1) / kCW);
