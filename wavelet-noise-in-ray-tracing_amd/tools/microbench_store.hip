@@ -409,6 +409,24 @@ int main(int argc, char **)
     float *out, *in;
     CK(hipMalloc(&out, bytes)); CK(hipMalloc(&in, bytes)); CK(hipMemset(in, 0, bytes));
     auto report = [&](const char *name, float ms, double b) { printf("%-34s %8.1f us  %7.1f GB/s\n", name, ms * 1e3, b / ms / 1e6); };
+    if (argc > 2) { // two arguments: sustained-load drift of the plain store stream (per-launch HIP events)
+        const int launches = 400;
+        std::vector<hipEvent_t> ev(launches + 1);
+        for (auto &e : ev) hipEventCreate(&e);
+        hipDeviceSynchronize();
+        hipEventRecord(ev[0]);
+        for (int i = 0; i < launches; ++i) {
+            fill_linear<false><<<256, 256>>>((float4 *)out, n / 4, 1.f);
+            hipEventRecord(ev[i + 1]);
+        }
+        hipDeviceSynchronize();
+        printf("fill_linear grid=256, %d back-to-back launches, us per launch:\n", launches);
+        for (int i = 0; i < launches; ++i) {
+            float t; hipEventElapsedTime(&t, ev[i], ev[i + 1]);
+            if (i < 10 || i % 20 == 0 || i >= launches - 5) printf("  launch %3d %7.1f\n", i, t * 1e3);
+        }
+        return 0;
+    }
     for (int fma : {0, 32, 64, 128}) {
         char nm[64];
         snprintf(nm, 64, "decoupled 8c+4s fma=%d", fma);
