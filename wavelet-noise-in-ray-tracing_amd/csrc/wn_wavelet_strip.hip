@@ -52,12 +52,12 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kCW = 4;          // compute waves per workgroup = rows per item
 constexpr int kSW = kCW;        // store waves per workgroup (one per compute wave)
 constexpr int kCols = 96;       // coefficient columns an item may touch (host: 255*step + 7 <= 96)
-constexpr int kPlanes = 38;     // coefficient planes an item may touch (host: (chunk_len-1)*step + 5 <= 38)
+constexpr int kPlanes = 37;     // coefficient planes an item may touch (host: (chunk_len-1)*step + 5 <= 37)
 constexpr int kRowFloats = 96;  // table row = kCols
-constexpr int kMaxChunk = 256;  // planes per item (z table: 16 B per plane)
+constexpr int kMaxChunk = 128;  // planes per item (z table: 16 B per plane)
 constexpr int kRRow = 100;      // one R row (96 columns + pad)
 constexpr int kTableFloats = kPlanes * kCW * kRowFloats; // the item's coefficient table [plane][tile row 0..3][96]
-constexpr int kStageFloats = 2 * kCW * 256; // two steps x one 1-KiB output row per compute wave
+constexpr int kStageFloats = 4 * kCW * 256; // two pairs of steps x one 1-KiB output row per compute wave and step
 constexpr int kZtabFloats = 4 * (kMaxChunk + 3);
 constexpr size_t kLdsBytes = (size_t)(kTableFloats + kStageFloats + kCW * 2 * kRRow + kZtabFloats) * sizeof(float);
 static_assert(2 * kLdsBytes <= 160 * 1024, "two workgroups share a CU");
@@ -120,9 +120,9 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
     float *const ztab = rrows + kCW * 2 * kRRow; // per plane of the item {mid_z, wz0, wz1, wz2}, + 3 pad entries
     const size_t plane_stride = (size_t)g.ny * g.nx;
     // Work: owner ranges (group of four rows, range of planes), walked in items.
-    // Every wave of the workgroup passes the same barriers.  Per item: one after its set-up, one per plane,
-    // one closing it.  Plane t: compute wave c parks its row in stage[t&1][c]; after the barrier store wave c
-    // moves it to memory while the compute waves are on t+1.
+    // Every wave of the workgroup passes the same barriers.  Per item: one after its set-up, one per pair of
+    // planes, one closing it.  Planes 2k, 2k+1: compute wave c parks its rows in stage[2k & 3][c], stage[(2k+1) & 3][c];
+    // after the next barrier store wave c moves both to memory while the compute waves are on the next pair.
     int gt = 0; // planes this workgroup has done: the priority turns follow it
 
     if (wave >= kCW) {
@@ -138,14 +138,17 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
             for (int zb = z_lo; zb < z_hi;) {
                 const int zn = min(a.chunk_len, z_hi - zb);
                 lds_barrier(); // set-up
-                for (int t = 0; t < zn; ++t, ++gt) {
-                    if ((gt & (kPrioPeriod - 1)) == 0) set_turn_priority(gt / kPrioPeriod);
+                for (int t = 0; t < zn; t += 2, gt += 2) { // a pair of planes per hand-over
+                    if ((gt & (kPrioPeriod - 1)) <= 1) set_turn_priority(gt / kPrioPeriod);
                     lds_barrier();
                     if (row < g.ny) {
-                        *reinterpret_cast<v4f *>(dst) = *reinterpret_cast<const v4f *>(src + (t & 1) * (kCW * 256));
-                        dst += plane_stride;
+                        *reinterpret_cast<v4f *>(dst) = *reinterpret_cast<const v4f *>(src + (t & 3) * (kCW * 256));
+                        if (t + 1 < zn)
+                            *reinterpret_cast<v4f *>(dst + plane_stride) = *reinterpret_cast<const v4f *>(src + ((t + 1) & 3) * (kCW * 256));
+                        dst += 2 * plane_stride;
                     }
                 }
+                if (zn & 1) --gt; // planes, not pairs
                 lds_barrier(); // item closed: stage, tables may be rewritten
                 zb += zn;
             }
@@ -312,11 +315,11 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
             // other buffer (with the hand-over of row z-1), then this plane's 16 window FMAs on `cur` (read a
             // step ago) and the parking of its row.  The two register sets alternate between the two halves
             // of the unrolled loop: no value is waited for in the step that requested it.
-            auto step = [&](int z, const float (&cur)[4], float (&nxt)[4], const v4f &e_use, v4f &e_load, int rd) {
+            auto step = [&](int z, const float (&cur)[4], float (&nxt)[4], const v4f &e_use, v4f &e_load, int rd, bool handover) {
                 const float *r = rb0 + rd * kRRow + wbase;
                 nxt[0] = r[0]; nxt[1] = r[1]; nxt[2] = r[2]; nxt[3] = r[3];
                 e_load = zt[z + 3];
-                if (z != 0) write_r_handover(rd ^ 1, e_use);
+                if (handover && z != 0) write_r_handover(rd ^ 1, e_use); // the two rows parked by the previous trip
                 else write_r(rd ^ 1, e_use);
                 float o[4];
 #pragma unroll
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
                     t = __builtin_fmaf(ww[q][2], cur[2], t);
                     o[q] = __builtin_fmaf(ww[q][3], cur[3], t);
                 }
-                *reinterpret_cast<v4f *>(park + (z & 1) * (kCW * 256)) = v4f{o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<v4f *>(park + (z & 3) * (kCW * 256)) = v4f{o[0], o[1], o[2], o[3]};
             };
             float wa[4], wb[4];
             v4f ea = zt[2], eb;
@@ -337,11 +340,11 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
             int z = 0;
             for (; z + 1 < zn; z += 2) {
                 if (((gt + z) & (kPrioPeriod - 1)) <= 1) set_turn_priority((gt + z) / kPrioPeriod); // two planes per trip
-                step(z, wa, wb, ea, eb, 1);
-                step(z + 1, wb, wa, eb, ea, 0);
+                step(z, wa, wb, ea, eb, 1, true);
+                step(z + 1, wb, wa, eb, ea, 0, false);
             }
-            if (z < zn) step(z, wa, wb, ea, eb, 1);
-            lds_barrier(); // hands over the last row
+            if (z < zn) step(z, wa, wb, ea, eb, 1, true);
+            lds_barrier(); // hands over the last pair of rows
             stamp();
             lds_barrier(); // item closed: stage, tables may be rewritten
             gt += zn;
