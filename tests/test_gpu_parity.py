@@ -364,6 +364,28 @@ def test_randomised_lattices_vs_oracle(wn, ora, noise3, tile3d_128, gold):
         assert (bits(exact) == bits(want)).all(), tag
 
 
+def test_randomised_strip_regime_vs_exact_kernel(wn, noise3, gold):
+    """Seeded sweep inside the strip-march kernel's regime (rows of k*256 samples, 0.18 <= step <= 1/3): steps,
+    row counts not divisible by 4, plane ranges that end inside an item, offsets beyond the tile period, a small
+    tile.  Checker: the exact kernel on the same lattice (bit-identical to the oracle in the tests above)."""
+    rng = np.random.default_rng(4099)
+    small = wn.WaveletNoise.from_coefficients(gold["tile3d_16_12345"], 3)
+    for case in range(24):
+        octave = int(rng.integers(2, 6))
+        step = float(rng.uniform(0.181, 0.332))
+        den = max(1, int(round(8.0 * 2.0 ** octave / step)))
+        nx = int(rng.choice([256, 512, 768, 1024]))
+        ny = int(rng.integers(1, 38))
+        nz = int(rng.choice([1, 2, 3, 31, 64, 127, 129, 200, 333]))
+        z0 = int(rng.choice([0, 5, 511, 4097, 100000]))
+        w = small if case % 4 == 3 else noise3
+        tag = (case, den, nx, ny, z0, nz, octave)
+        fast = wn.wavelet_volume(w, den, nx, ny, z0, z0 + nz, octave)
+        exact = wn.wavelet_volume(w, den, nx, ny, z0, z0 + nz, octave, exact=True)
+        err = float((fast - exact).abs().max())
+        assert err <= TOL, (tag, err)
+
+
 def test_generic_grid_descriptor_negative_and_constant_axes(wn, ora, noise3, tile3d_128):
     """Unusual descriptors: negative range and steps > 1/3 cell go to the direct kernel
     (bit-identical); a zero step (all samples on one point) stays within tolerance."""
