@@ -380,10 +380,14 @@ int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_
     const long long groups = (long long)(g.nx / 256) * ((g.ny + kCW - 1) / kCW);
     if (groups > 0x3fffffffLL) return WN_OK;
 
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        cus = prop.multiProcessorCount;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static int cus_device = -1, cus = 256; // one process drives one GPU: queried once
+    if (cus_device != dev) {
+        hipDeviceProp_t prop;
+        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cus_device = dev;
+    }
     // items: the planes an item touches must fit its LDS table
     int chunk_max = kMaxChunk;
     if (step > 0.0) chunk_max = (int)std::min<double>(kMaxChunk, std::floor((kPlanes - 5 - slack) / step) + 1.0);
