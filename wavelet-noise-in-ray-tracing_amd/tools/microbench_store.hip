@@ -273,10 +273,12 @@ __global__ __launch_bounds__(256) void fill_strips4_work(float *out, int N, floa
 // outstanding global store of the wave to complete
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int CW, int SW>
+template <int CW, int SW, int MAP = 0, int LDS_PAD = 0>
 __global__ __launch_bounds__(64 * (CW + SW)) void fill_decoupled(float *out, int N, float v, int fma)
 {
     __shared__ v4f stage[2][CW][64];
+    __shared__ float pad[LDS_PAD + 1]; // LDS_PAD floats of ballast: limits the workgroups per CU like the real kernel's tables
+    if (LDS_PAD && threadIdx.x == 0 && fma < 0) pad[LDS_PAD] = v;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int steps = N / 2, segs = N * 2;
     const int base = blockIdx.x * CW;
@@ -299,7 +301,12 @@ __global__ __launch_bounds__(64 * (CW + SW)) void fill_decoupled(float *out, int
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int item = base + s * PER + k, chunk = item / segs, seg = item - chunk * segs;
-            const int y = seg >> 1, half = seg & 1;
+            int y = seg >> 1, half = seg & 1;
+            if (MAP == 1) { // the strip kernel's items: four rows of one column block per workgroup
+                const int grp = seg / CW, c = seg - grp * CW;
+                y = (grp >> 1) * CW + c;
+                half = grp & 1;
+            }
             dst[k] = reinterpret_cast<v4f *>(out + ((size_t)(chunk * steps) * N + y) * N + half * 256) + lane;
         }
         const size_t plane4 = (size_t)N * N / 4;
@@ -427,7 +434,7 @@ int main(int argc, char **)
         }
         return 0;
     }
-    for (int fma : {0, 32, 64, 128}) {
+    for (int fma : {0, 32}) {
         char nm[64];
         snprintf(nm, 64, "decoupled 8c+4s fma=%d", fma);
         report(nm, time_it([&] { fill_decoupled<8, 4><<<256, 768>>>(out, N, 1.f, fma); }, 20), bytes);
@@ -435,6 +442,12 @@ int main(int argc, char **)
         report(nm, time_it([&] { fill_decoupled<8, 8><<<256, 1024>>>(out, N, 1.f, fma); }, 20), bytes);
         snprintf(nm, 64, "decoupled 4c+4s fma=%d (2 WG per CU)", fma);
         report(nm, time_it([&] { fill_decoupled<4, 4><<<512, 512>>>(out, N, 1.f, fma); }, 20), bytes);
+        snprintf(nm, 64, "decoupled 4c+4s rows4 map fma=%d", fma);
+        report(nm, time_it([&] { fill_decoupled<4, 4, 1><<<512, 512>>>(out, N, 1.f, fma); }, 20), bytes);
+        snprintf(nm, 64, "decoupled 4c+4s rows4 +72KB LDS fma=%d", fma);
+        report(nm, time_it([&] { fill_decoupled<4, 4, 1, 15000><<<512, 512>>>(out, N, 1.f, fma); }, 20), bytes);
+        snprintf(nm, 64, "decoupled 4c+4s +72KB LDS fma=%d", fma);
+        report(nm, time_it([&] { fill_decoupled<4, 4, 0, 15000><<<512, 512>>>(out, N, 1.f, fma); }, 20), bytes);
         snprintf(nm, 64, "decoupled ring 8c+4s K=8 fma=%d", fma);
         report(nm, time_it([&] { fill_decoupled_ring<8, 4, 8><<<256, 768>>>(out, N, 1.f, fma); }, 20), bytes);
         snprintf(nm, 64, "decoupled ring 8c+4s K=4 fma=%d", fma);
