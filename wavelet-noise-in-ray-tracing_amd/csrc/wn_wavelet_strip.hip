@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
             }
             const int planes = min(m_last - m0 + 3, kPlanes); // the host guarantees the bound
             {
-                constexpr int kBatch = 12; // the whole table of a 128-plane item at step 1/4 in one round trip
+                constexpr int kBatch = 8;
                 const int total = planes * kCW * nquads; // (plane, tile row, quad) triples
                 for (int q0 = 0; q0 < total; q0 += kBatch * 64 * kCW) {
                     v4f c[kBatch];
