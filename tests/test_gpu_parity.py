@@ -207,6 +207,8 @@ def test_strip_path_vs_oracle(wn, ora, noise3, tile3d_128, den, nx, ny, z0, z1, 
 @pytest.mark.parametrize("den,nx,ny,z0,z1", [
     (512, 512, 300, 0, 512),        # 2400 items on 2048 wave slots: second-round items change segment
     (512, 768, 170, 3, 260),        # ragged last chunk, 3 column blocks, odd row count
+    (512, 512, 2048, 1, 255),       # 1024 groups: one range of 254 planes walked in two items of 127 (odd)
+    (400, 256, 2052, 0, 301),       # step .32: 513 groups, a range of 301 planes in items of 76, 75, 75, 75
 ])
 def test_strip_path_many_items_vs_exact_kernel(wn, noise3, den, nx, ny, z0, z1):
     """More items than resident compute waves.  Checker: the exact kernel (bit-identical to the oracle,

@@ -133,10 +133,10 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
             const int yg = grp / a.segs_per_row, xs = grp - yg * a.segs_per_row;
             const int z_lo = range * a.range_len, z_hi = min(g.nz, z_lo + a.range_len);
             const int row = yg * kCW + c; // the last group of a lattice with ny % 4 != 0 has rows past the end: computed, not stored
-            float *dst = a.out + ((size_t)z_lo * plane_stride + (size_t)row * g.nx + xs * 256 + lane * 4);
             const float *src = stage + c * 256 + lane * 4;
             for (int zb = z_lo; zb < z_hi;) {
                 const int zn = min(a.chunk_len, z_hi - zb);
+                float *dst = a.out + ((size_t)zb * plane_stride + (size_t)row * g.nx + xs * 256 + lane * 4);
                 lds_barrier(); // set-up
                 for (int t = 0; t < zn; t += 2, gt += 2) { // a pair of planes per hand-over
                     if ((gt & (kPrioPeriod - 1)) <= 1) set_turn_priority(gt / kPrioPeriod);
