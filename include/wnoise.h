@@ -18,7 +18,17 @@
  *     all output buffers.  `stream` is a hipStream_t passed as void* (NULL = default stream);
  *     compute entry points only enqueue work on it and never synchronise.
  *   - Handles (wn_tile, wn_perm) are immutable after creation, so evaluation is re-entrant,
- *     like the reference's const evaluate* / noise() members.
+ *     like the reference's const evaluate* / noise() members, and entry points may be called
+ *     from several host threads and for several devices (per-device facts are kept in
+ *     mutex-protected tables; a handle must be used on the device it was created on, otherwise
+ *     WN_ERR_INVALID).
+ *   - rand(): the HIP runtime draws from the C library's global rand() state while it launches.
+ *     Every entry point parks the application's state while any thread is inside the library
+ *     (depth-counted under a mutex) and restores it when the last call returns, so a caller
+ *     that uses rand() between calls (the reference's renderer, main.cpp:184-185) sees the
+ *     stream it would see without the library.  An application thread that calls rand()
+ *     CONCURRENTLY with another thread's ABI call draws from the library's private state:
+ *     rand() is one process-global stream.
  *   - Value-level conventions kept from the reference: an empty tile evaluates to 0.0f
  *     (WaveletNoise.cpp:112,186,219); an odd tile size is bumped to the next even size
  *     (WaveletNoise.cpp:22-25); NaN / |coordinate| >= 2^31 inputs are undefined as in the

@@ -93,3 +93,18 @@ def test_band_limits_of_gpu_grids_with_rocfft(fm):
     vol = wn.wavelet_volume(n3, 512, 512, 512, 100, 101, 4)[0]
     prof, peak = fm.radial_power_spectrum(vol)
     assert fm.band_energy_fraction(prof, 0, 24) < 0.35  # step .25: band at radii [64,128] of 512 px
+
+
+def test_converter_size_mismatch_and_missing_input_follow_the_reference(fm, tmp_path):
+    """threejs/convert_raw_to_json.py:23-25 (missing file -> False), :36-39 (count != image_size^2 ->
+    image_size = int(sqrt(count)), square document), :42/:88-90 (no perfect square -> False)."""
+    assert fm.convert_raw_to_json(str(tmp_path / "nope.raw"), str(tmp_path / "nope.json"), 256) is False
+    assert not (tmp_path / "nope.json").exists()
+    a = np.arange(64 * 64, dtype=np.float32)
+    a.tofile(tmp_path / "small.raw")
+    assert fm.convert_raw_to_json(str(tmp_path / "small.raw"), str(tmp_path / "small.json"), 256) is True
+    doc = json.load(open(tmp_path / "small.json"))
+    assert doc["width"] == 64 and doc["height"] == 64 and len(doc["data"]) == 64 * 64
+    assert doc["original_range"]["max"] == 4095.0 and doc["data"][-1] == 1.0
+    np.arange(50, dtype=np.float32).tofile(tmp_path / "ragged.raw")
+    assert fm.convert_raw_to_json(str(tmp_path / "ragged.raw"), str(tmp_path / "ragged.json"), 256) is False

@@ -33,10 +33,10 @@ def shas():
     return json.load(open(os.path.join(GOLD, "artefacts.json")))["raw"]
 
 
-def test_gridgen_exact_reproduces_all_15_committed_files(tmp_path, shas):
+def test_gridgen_reproduces_all_15_committed_files_by_default(tmp_path, shas):
     exe = os.path.join(PKG, "tools", "gridgen")
     assert os.path.exists(exe), "run __graft_entry__.build()"
-    out = subprocess.run([exe, str(tmp_path / "raw"), "--exact"], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, str(tmp_path / "raw")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     for octave in (3, 4, 5):
         for n in NAMES:
@@ -44,9 +44,9 @@ def test_gridgen_exact_reproduces_all_15_committed_files(tmp_path, shas):
             assert sha(tmp_path / "raw" / f) == shas[f], f
 
 
-def test_gridgen_default_path(tmp_path, shas):
+def test_gridgen_fast_path(tmp_path, shas):
     exe = os.path.join(PKG, "tools", "gridgen")
-    out = subprocess.run([exe, str(tmp_path / "raw")], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, str(tmp_path / "raw"), "--fast"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     for octave in (3, 4, 5):
         for n in NAMES:

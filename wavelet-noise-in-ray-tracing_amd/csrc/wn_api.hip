@@ -5,28 +5,102 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <numeric>
 #include <random>
+#include <utility>
 #include <vector>
 
 namespace wn {
 
 static char g_private_rand_state[256];
-static std::once_flag g_rand_once;
+static std::mutex g_rand_mu;
+static int g_rand_depth = 0;         // ABI calls (of all threads, nested ones included) inside a guarded region
+static char *g_rand_caller = nullptr; // the application's state, parked while g_rand_depth > 0
 
+// The caller's state is parked by the first call that enters the library and put back by the last one
+// that leaves, under a mutex: two host threads inside the library can no longer hand each other the
+// private state as "caller state" (ADVICE round 1).  A thread that calls rand() itself while another
+// thread is inside the library still draws from the private state -- rand() is one process-global
+// stream; wnoise.h says so.
 RandStateGuard::RandStateGuard()
 {
-    std::call_once(g_rand_once, [] {
-        char *app = initstate(0x776e6f69u, g_private_rand_state, sizeof(g_private_rand_state));
-        setstate(app); // initstate switched to the private state: hand the caller's back
-    });
-    saved_ = setstate(g_private_rand_state);
+    std::lock_guard<std::mutex> lock(g_rand_mu);
+    if (g_rand_depth++ == 0) {
+        static bool initialised = false;
+        if (!initialised) {
+            // initstate switches to the new state and returns the previous (= the caller's) one
+            g_rand_caller = initstate(0x776e6f69u, g_private_rand_state, sizeof(g_private_rand_state));
+            initialised = true;
+        } else {
+            g_rand_caller = setstate(g_private_rand_state);
+        }
+    }
 }
 
 RandStateGuard::~RandStateGuard()
 {
-    if (saved_) setstate(saved_);
+    std::lock_guard<std::mutex> lock(g_rand_mu);
+    if (--g_rand_depth == 0 && g_rand_caller) {
+        setstate(g_rand_caller);
+        g_rand_caller = nullptr;
+    }
+}
+
+// ---- per-device facts (mutex-protected tables keyed by device ordinal) ---------------------------
+static std::mutex g_dev_mu;
+static std::map<int, int> g_dev_cus;
+static std::map<std::pair<const void *, int>, size_t> g_lds_optin; // (kernel, device) -> bytes granted
+
+int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return dev;
+}
+
+int device_compute_units(int dev)
+{
+    std::lock_guard<std::mutex> lock(g_dev_mu);
+    auto it = g_dev_cus.find(dev);
+    if (it != g_dev_cus.end()) return it->second;
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    else
+        (void)hipGetLastError();
+    g_dev_cus[dev] = cus;
+    return cus;
+}
+
+bool ensure_dynamic_lds(const void *kernel, int dev, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_dev_mu);
+    const auto key = std::make_pair(kernel, dev);
+    auto it = g_lds_optin.find(key);
+    if (it != g_lds_optin.end() && it->second >= bytes) return true;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", bytes, hipGetErrorString(e));
+        return false;
+    }
+    g_lds_optin[key] = bytes;
+    return true;
+}
+
+int check_handle_device(int handle_device, const char *what)
+{
+    const int dev = current_device();
+    if (dev != handle_device)
+        return fail(WN_ERR_INVALID, "%s was created on device %d but the current device is %d", what,
+                    handle_device, dev);
+    return WN_OK;
 }
 
 static thread_local char g_err[512] = "";

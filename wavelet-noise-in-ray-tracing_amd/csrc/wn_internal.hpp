@@ -48,15 +48,14 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 // renderer is deterministic only through the unseeded global rand() (main.cpp:184-185,
 // rtweekend.h:37-40), so every ABI entry point parks the caller's random state and lets HIP
 // consume a private one; the caller's stream is exactly what it would be without the library.
+// Depth-counted under a mutex: the state is parked by the first ABI call that enters the library
+// (from any thread) and restored by the last one that leaves.
 class RandStateGuard {
   public:
     RandStateGuard();
     ~RandStateGuard();
     RandStateGuard(const RandStateGuard &) = delete;
     RandStateGuard &operator=(const RandStateGuard &) = delete;
-
-  private:
-    char *saved_;
 };
 #define WN_ENTRY() ::wn::RandStateGuard wn_rand_state_guard_
 
@@ -83,6 +82,16 @@ struct GridArgs {
 };
 
 int check_grid(const wn_grid *g, bool needs_z, GridArgs *out);
+
+// Per-device facts, kept in mutex-protected tables keyed by the device ordinal (a host may drive
+// several devices from several threads).
+int current_device();
+int device_compute_units(int dev);
+// Opt `kernel` in to `bytes` of dynamic LDS on device `dev` (needed beyond 64 KiB), once per
+// (kernel, device).  false = the runtime refused: the caller falls back to another kernel.
+bool ensure_dynamic_lds(const void *kernel, int dev, size_t bytes);
+// WN_ERR_INVALID unless the handle (tile / perm) lives on the current device.
+int check_handle_device(int handle_device, const char *what);
 
 // wn_wavelet_strip.hip: launches the strip-march kernel when the lattice is in its regime.
 int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_t stream, bool *launched);

@@ -185,6 +185,7 @@ int perlin_grid(const wn_perm *perm, const wn_grid *grid, int kind, int depth, f
     int rc = wn::require_device();
     if (rc) return rc;
     if (!perm) return wn::fail(WN_ERR_INVALID, "perm is NULL");
+    if ((rc = wn::check_handle_device(perm->device, "perm")) != WN_OK) return rc;
     GridArgs g;
     rc = wn::check_grid(grid, true, &g);
     if (rc) return rc;
@@ -205,6 +206,7 @@ int perlin_points(const wn_perm *perm, const double *p64, const float *p32, size
     int rc = wn::require_device();
     if (rc) return rc;
     if (!perm) return wn::fail(WN_ERR_INVALID, "perm is NULL");
+    if ((rc = wn::check_handle_device(perm->device, "perm")) != WN_OK) return rc;
     if (n == 0) return WN_OK;
     if ((!p64 && !p32) || !out_dev) return wn::fail(WN_ERR_INVALID, "points/out pointer is NULL");
     PerlinPointsArgs a{perm->dev, p64, p32, out_dev, n, kind, depth};
@@ -268,6 +270,7 @@ int wn_noise_texture_points(const wn_perm *perm, double scale, int octave, const
     int rc = wn::require_device();
     if (rc) return rc;
     if (!perm) return wn::fail(WN_ERR_INVALID, "perm is NULL");
+    if ((rc = wn::check_handle_device(perm->device, "perm")) != WN_OK) return rc;
     if (n == 0) return WN_OK;
     if (!xyz_dev || !grey_dev) return wn::fail(WN_ERR_INVALID, "points/grey pointer is NULL");
     NoiseTexArgs a{};

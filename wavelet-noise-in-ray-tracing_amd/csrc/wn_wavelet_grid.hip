@@ -554,6 +554,7 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
     if (tile->n == 0 || nbands < 1 || nbands > kMaxBands) return false;
     if (pow2_mask(tile->n) < 0) return false; // the brick kernel wraps with a mask: power-of-two tiles
     if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0) return false;
+    if (!g.z_const_mode && g.z0 < 0) return false; // negative plane indices: the exact kernel (bounds below assume indices >= 0)
     const int BZ = g.nz >= kMaxBZ ? kMaxBZ : ceil_pow2(g.nz);
     const int rows = kBrickY * BZ;
     const double zmax = g.z_const_mode ? 0.0 : (double)g.z0 + g.nz;
@@ -603,24 +604,11 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
     return true;
 }
 
-int compute_units()
-{
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
-
 // Persistent grid: k workgroups per CU, k chosen (within what LDS and the 32-wave limit admit)
 // so that the bricks divide as evenly as possible over the workgroups.
 int persistent_grid(long long items, size_t lds_bytes, int xw)
 {
-    const int cus = compute_units();
+    const int cus = wn::device_compute_units(wn::current_device());
     int kmax = (int)((160 * 1024) / (lds_bytes + 2048));
     const int wave_cap = 8 / xw; // 32 waves per CU
     kmax = kmax > wave_cap ? wave_cap : (kmax < 1 ? 1 : kmax);
@@ -637,40 +625,40 @@ int persistent_grid(long long items, size_t lds_bytes, int xw)
 }
 
 template <int NB, int XW>
-void launch_sep2(const SepArgs &a, size_t lds, hipStream_t s)
+bool launch_sep2(const SepArgs &a, size_t lds, hipStream_t s)
 {
     const long long items = (long long)a.nbx * a.nby * a.nbz;
-    static int big_lds_device = -1; // dynamic LDS beyond 64 KiB needs a per-device opt-in for this kernel
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (lds > 48 * 1024 && big_lds_device != dev) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&grid3d_sep_kernel<NB, XW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        big_lds_device = dev;
-    }
+    // dynamic LDS beyond 64 KiB needs a per-(kernel, device) opt-in
+    if (lds > 48 * 1024 &&
+        !wn::ensure_dynamic_lds(reinterpret_cast<const void *>(&grid3d_sep_kernel<NB, XW>), wn::current_device(), 128 * 1024))
+        return false;
     hipLaunchKernelGGL((grid3d_sep_kernel<NB, XW>), dim3(persistent_grid(items, lds, XW)),
                        dim3(256 * XW), lds, s, a);
+    return true;
 }
 
 template <int NB>
-void launch_sep(const SepArgs &a, size_t lds, hipStream_t s)
+bool launch_sep(const SepArgs &a, size_t lds, hipStream_t s)
 {
-    if (a.xw == 2) launch_sep2<NB, 2>(a, lds, s);
-    else launch_sep2<NB, 1>(a, lds, s);
+    return a.xw == 2 ? launch_sep2<NB, 2>(a, lds, s) : launch_sep2<NB, 1>(a, lds, s);
 }
 
-int run_sep(const SepArgs &a, size_t lds, hipStream_t s)
+// *launched = false: the runtime refused the LDS opt-in; the caller falls back to the direct kernel.
+int run_sep(const SepArgs &a, size_t lds, hipStream_t s, bool *launched)
 {
+    bool ok;
     switch (a.nbands) {
-    case 1: launch_sep<1>(a, lds, s); break;
-    case 2: launch_sep<2>(a, lds, s); break;
-    case 3: launch_sep<3>(a, lds, s); break;
-    case 4: launch_sep<4>(a, lds, s); break;
-    case 5: launch_sep<5>(a, lds, s); break;
-    case 6: launch_sep<6>(a, lds, s); break;
-    case 7: launch_sep<7>(a, lds, s); break;
-    default: launch_sep<8>(a, lds, s); break;
+    case 1: ok = launch_sep<1>(a, lds, s); break;
+    case 2: ok = launch_sep<2>(a, lds, s); break;
+    case 3: ok = launch_sep<3>(a, lds, s); break;
+    case 4: ok = launch_sep<4>(a, lds, s); break;
+    case 5: ok = launch_sep<5>(a, lds, s); break;
+    case 6: ok = launch_sep<6>(a, lds, s); break;
+    case 7: ok = launch_sep<7>(a, lds, s); break;
+    default: ok = launch_sep<8>(a, lds, s); break;
     }
+    *launched = ok;
+    if (!ok) return WN_OK;
     WN_LAUNCH_CHECK("grid3d_sep_kernel");
     return WN_OK;
 }
@@ -687,6 +675,7 @@ int wn_eval3d_grid(const wn_tile *tile, const wn_grid *grid, float *out_dev, voi
     int rc = require_device();
     if (rc) return rc;
     if (!tile) return fail(WN_ERR_INVALID, "tile is NULL");
+    if (tile->count && (rc = check_handle_device(tile->device, "tile")) != WN_OK) return rc;
     if (tile->count && tile->dims != 3) return fail(WN_ERR_INVALID, "wn_eval3d_grid needs a 3-D tile");
     GridArgs g;
     rc = check_grid(grid, true, &g);
@@ -705,7 +694,8 @@ int wn_eval3d_grid(const wn_tile *tile, const wn_grid *grid, float *out_dev, voi
         if (plan_sep(tile, g, 1, &os, nullptr, 1.0f, &a, &lds)) {
             a.out = out_dev;
             a.vec4_ok = (g.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
-            return run_sep(a, lds, as_stream(stream));
+            rc = run_sep(a, lds, as_stream(stream), &launched);
+            if (rc || launched) return rc;
         }
     }
     DirectArgs d{};
@@ -733,6 +723,7 @@ int wn_multiband3d_grid(const wn_tile *tile, const wn_grid *grid, float s, int f
     int rc = require_device();
     if (rc) return rc;
     if (!tile) return fail(WN_ERR_INVALID, "tile is NULL");
+    if (tile->count && (rc = check_handle_device(tile->device, "tile")) != WN_OK) return rc;
     if (tile->count && tile->dims != 3) return fail(WN_ERR_INVALID, "wn_multiband3d_grid needs a 3-D tile");
     if (nbands < 0 || nbands > kMaxBands)
         return fail(WN_ERR_INVALID, "nbands must be in 0..%d (got %d)", kMaxBands, nbands);
@@ -760,7 +751,9 @@ int wn_multiband3d_grid(const wn_tile *tile, const wn_grid *grid, float s, int f
         oscale[b] = g.octave_scale * bscale[b];
     }
 
-    if (!(grid->flags & WN_GRID_EXACT) && active >= 1 && g.post_scale == 1.0f) {
+    // z_mode == WN_Z_CONST: band b sits at 2*z_const*2^(first_band+b), which the brick kernel's per-band
+    // tables do not model (they scale lattice indices, not a constant) -> the direct kernel
+    if (!(grid->flags & WN_GRID_EXACT) && active >= 1 && g.post_scale == 1.0f && !g.z_const_mode) {
         SepArgs a{};
         size_t lds = 0;
         GridArgs gb = g;
@@ -768,7 +761,9 @@ int wn_multiband3d_grid(const wn_tile *tile, const wn_grid *grid, float s, int f
         if (plan_sep(tile, gb, active, oscale, wts, out_div, &a, &lds)) {
             a.out = out_dev;
             a.vec4_ok = (g.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
-            return run_sep(a, lds, as_stream(stream));
+            bool launched = false;
+            rc = run_sep(a, lds, as_stream(stream), &launched);
+            if (rc || launched) return rc;
         }
     }
     DirectArgs d{};
@@ -806,6 +801,7 @@ int wn_eval2d_grid(const wn_tile *tile, const wn_grid *grid, float *out_dev, voi
     int rc = require_device();
     if (rc) return rc;
     if (!tile) return fail(WN_ERR_INVALID, "tile is NULL");
+    if (tile->count && (rc = check_handle_device(tile->device, "tile")) != WN_OK) return rc;
     if (tile->count && tile->dims != 2) return fail(WN_ERR_INVALID, "wn_eval2d_grid needs a 2-D tile");
     GridArgs g;
     rc = check_grid(grid, false, &g);
@@ -832,6 +828,7 @@ int wn_eval3d_projected_grid(const wn_tile *tile, const wn_grid *grid, const flo
     int rc = require_device();
     if (rc) return rc;
     if (!tile || !normal) return fail(WN_ERR_INVALID, "tile/normal is NULL");
+    if (tile->count && (rc = check_handle_device(tile->device, "tile")) != WN_OK) return rc;
     if (tile->count && tile->dims != 3)
         return fail(WN_ERR_INVALID, "wn_eval3d_projected_grid needs a 3-D tile");
     GridArgs g;

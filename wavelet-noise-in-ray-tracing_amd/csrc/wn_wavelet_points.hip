@@ -198,6 +198,10 @@ int fill_common(const wn_tile *tile, int dims, const void *pts, size_t n, const 
                 PointsArgs *a)
 {
     if (!tile) return wn::fail(WN_ERR_INVALID, "tile is NULL");
+    if (tile->count) {
+        const int rc = wn::check_handle_device(tile->device, "tile");
+        if (rc) return rc;
+    }
     if (tile->count && tile->dims != dims)
         return wn::fail(WN_ERR_INVALID, "tile is %d-D, this entry point needs %d-D", tile->dims, dims);
     if (n && (!pts || !out)) return wn::fail(WN_ERR_INVALID, "points/out pointer is NULL");
@@ -316,6 +320,7 @@ int wn_wavelet_texture_points(const wn_tile *tile, int use_3d, double scale, int
     if (!xyz_dev || !grey_dev) return fail(WN_ERR_INVALID, "points/grey pointer is NULL");
     TexArgs a{};
     const bool has_tile = tile && tile->count != 0;
+    if (has_tile && (rc = check_handle_device(tile->device, "tile")) != WN_OK) return rc;
     if (has_tile && tile->dims != (use_3d ? 3 : 2))
         return fail(WN_ERR_INVALID, "tile is %d-D but use_3d=%d", tile->dims, use_3d);
     a.coef = has_tile ? tile->dev : nullptr;

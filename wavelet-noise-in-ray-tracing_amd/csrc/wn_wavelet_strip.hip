@@ -298,6 +298,14 @@ __global__ __launch_bounds__(64 * (kCW + kSW)) void grid3d_strip_kernel(const St
             // statement: the counted wait leaves only these R writes outstanding (LDS operations of a wave
             // complete in issue order), so the barrier does not wait out an LDS write latency.  hipcc does not
             // count the hidden writes; unknown operations can only make its own waits stricter.
+            // Two inline-asm hazards that each cost a GPU fault while this kernel was developed -- keep them out:
+            //  (1) never tie a register that a still-in-flight load writes to a wait statement with "+v"
+            //      (asm volatile("s_waitcnt vmcnt(N)" : "+v"(loaded))): hipcc may copy the register BEFORE the
+            //      statement, i.e. before the data has landed.  Operands of the statement below are inputs only
+            //      ("v"), produced by VALU, never by a pending memory operation;
+            //  (2) a VMEM instruction inside asm that reads an SGPR written by v_readfirstlane just before needs
+            //      its own "s_nop 4" (the compiler does not see the hazard through the asm).  This kernel has no
+            //      VMEM instruction in asm; its only asm statements are LDS writes, waits and barriers.
             auto write_r_handover = [&](int buf, const v4f e) {
                 float ra, rb;
                 r_values(e, ra, rb);
@@ -365,6 +373,7 @@ int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_
     *launched = false;
     if (tile->n < 4 || pow2_mask(tile->n) < 0) return WN_OK;
     if (g.z_const_mode || g.nx <= 0 || g.ny <= 0 || g.nz <= 0) return WN_OK;
+    if (g.z0 < 0) return WN_OK; // negative plane indices: the exact kernel (the bounds below assume indices >= 0)
     if (g.nx % 256 != 0 || (reinterpret_cast<uintptr_t>(out_dev) & 15) != 0) return WN_OK;
     const double step = (double)g.base_range * (double)g.octave_scale * (double)g.post_scale / g.den;
     if (!(step >= 0.0) || !std::isfinite(step)) return WN_OK;
@@ -380,14 +389,8 @@ int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_
     const long long groups = (long long)(g.nx / 256) * ((g.ny + kCW - 1) / kCW);
     if (groups > 0x3fffffffLL) return WN_OK;
 
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    static int cus_device = -1, cus = 256; // one process drives one GPU: queried once
-    if (cus_device != dev) {
-        hipDeviceProp_t prop;
-        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-        cus_device = dev;
-    }
+    const int dev = current_device();
+    const int cus = device_compute_units(dev);
     // items: the planes an item touches must fit its LDS table
     int chunk_max = kMaxChunk;
     if (step > 0.0) chunk_max = (int)std::min<double>(kMaxChunk, std::floor((kPlanes - 5 - slack) / step) + 1.0);
@@ -412,12 +415,8 @@ int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_
     // a range is walked in equal items of at most chunk_max planes
     const int per_range = (a.range_len + chunk_max - 1) / chunk_max;
     a.chunk_len = (a.range_len + per_range - 1) / per_range;
-    static int big_lds_device = -1; // dynamic LDS beyond 64 KiB needs a per-device opt-in for this kernel
-    if (big_lds_device != dev) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&grid3d_strip_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-        big_lds_device = dev;
-    }
+    // dynamic LDS beyond 64 KiB needs a per-(kernel, device) opt-in; refused -> the brick kernel serves the lattice
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(&grid3d_strip_kernel), dev, kLdsBytes)) return WN_OK;
     const int blocks = (int)std::min<long long>(owners, wgs);
 #ifdef WN_STRIP_STAMPS
     static unsigned long long *dbg = nullptr;

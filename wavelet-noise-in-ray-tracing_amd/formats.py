@@ -37,7 +37,17 @@ def raw_to_json_dict(grid):
 
 
 def convert_raw_to_json(raw_file_path, json_file_path, image_size=256):
-    grid = read_raw(raw_file_path, image_size)
+    """threejs/convert_raw_to_json.py:12-90.  A missing input returns False (:23-25); a float count
+    other than image_size^2 re-derives image_size = int(sqrt(count)) (:36-39) and writes that square;
+    a count that is no perfect square cannot be reshaped there (:42, caught at :88-90) -> False."""
+    if not os.path.exists(raw_file_path):
+        return False
+    a = np.fromfile(raw_file_path, dtype="<f4")
+    if a.size != image_size * image_size:
+        image_size = int(np.sqrt(a.size))
+    if a.size == 0 or a.size != image_size * image_size:
+        return False
+    grid = a.reshape(image_size, image_size)
     out_dir = os.path.dirname(json_file_path)
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)
