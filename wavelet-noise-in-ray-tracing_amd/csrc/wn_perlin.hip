@@ -9,6 +9,7 @@
 // not HBM bound.
 #include "wn_internal.hpp"
 #include "wn_device_eval.hpp"
+#include "wn_perlin_run.hpp"
 
 #include <cmath>
 
@@ -23,9 +24,12 @@ struct PerlinGridArgs {
     float *out;
     GridArgs g;
     int kind, depth;
+    int vec4_ok; // rows start 16-byte aligned (nx % 4 == 0 and an aligned output pointer)
 };
 
-__global__ __launch_bounds__(256) void perlin_grid_kernel(const PerlinGridArgs a)
+// Generic dense-grid kernel: one sample per lane, every sample hashes for itself.  Serves what the
+// run kernel below does not (narrow grids, depth 0 or > kRunMaxDepth).
+__global__ __launch_bounds__(256) void perlin_grid_generic_kernel(const PerlinGridArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_perm[512];
     wn::load_perm_lds(s_perm, a.perm);
@@ -49,6 +53,213 @@ __global__ __launch_bounds__(256) void perlin_grid_kernel(const PerlinGridArgs a
         else if (a.kind == kTurb) v = wn::perlin_turb(perm, px, py, pz, a.depth);
         else v = wn::perlin_fractal(perm, px, py, pz);
         a.out[e] = (float)v * g.out_scale;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// perlin_grid_run_kernel -- dense grids built around what consecutive samples of an axis-aligned
+// lattice SHARE (perlin.h:42-62 evaluated for a whole block):
+//   * everything per axis is per axis: floor / fractional part / fade of a coordinate depend on one
+//     index only.  A workgroup (8 waves) owns 512 x samples x kRunTY rows x <= kRunTZ planes and first
+//     tabulates, per octave, {xf, fade(xf)} and the cell index X for its 512 x samples and the same for
+//     its rows and planes (LDS; fp64, the reference's operation order);
+//   * a lane walks a RUN of 8 consecutive x samples of one row.  The eight corner hashes
+//     p[p[p[X]+Y]+Z] ... (perlin.h:55-61: 14 table look-ups) and everything derived from them are
+//     computed once per cell the run enters (at the BASELINE lattice -- step 1/8 per sample -- once
+//     per run), not once per sample;
+//   * grad() (perlin.h:26-31) picks two of (x,y,z) and two signs from the low 4 hash bits.  Inside a
+//     run only x moves, so a corner's gradient is  (+-dx | nothing) + K  with K = (+-dy) + (+-dz),
+//     +-dy or +-dz, a per-row constant.  Per row and octave the wave builds a 64-entry LDS table
+//     [cy][cz][h] -> {K, and-mask, sign-xor} with one lane per entry; a lane fetches its 8 corners'
+//     entries with 8 ds_read_b128.  "Nothing" is -0.0, the identity of IEEE addition for every K
+//     including both zeros, so each gradient is the single rounded addition the reference performs
+//     (its two operands commute) and lattice points keep the reference's zero signs.
+//   * per sample what is left is 8 x (2 and + 1 xor + 1 fp64 add) for the gradients and the 7 lerps
+//     (21 fp64 ops, unfused, reference order): 30-32 fp64 + 24 integer VALU instructions per sample
+//     and octave instead of ~60 + ~170.
+// turb / fractal_noise loop octaves per row with the running sums of the 8 samples in registers, in
+// the reference's accumulation order.  Results are bit-identical to perlin_exact / the CPU classes.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRunMaxDepth = 8;
+constexpr int kRunX = 512;  // x samples per workgroup (64 lanes x 8)
+constexpr int kRunTY = 8;   // rows ...
+constexpr int kRunTZ = 8;   // ... and planes per workgroup
+constexpr int kRun = 8;     // samples per lane and row
+// Waves per workgroup (template parameter W): they share the block's axis tables (57 KB at 7 octaves) and
+// each adds 5 KB of its own, so deep turb runs 16 waves on one set of tables (4 waves per SIMD) where two
+// 8-wave workgroups would not fit a CU's LDS; shallow grids use 8 (three workgroups per CU).
+
+struct RunAxisEntry {
+    double f, fade; // fractional part and its fade()
+};
+using wn::RunKEntry;
+
+__host__ __device__ constexpr size_t run_lds_bytes(int depth, int kRunWaves)
+{
+    return 512 /* perm */ + (size_t)depth * kRunX * sizeof(RunAxisEntry) + (size_t)depth * kRunX /* x cells */ +
+           (size_t)depth * (kRunTY + kRunTZ) * (sizeof(RunAxisEntry) + sizeof(int)) + kRunWaves * 64 * sizeof(RunKEntry) +
+           kRunWaves * kRun * 64 * sizeof(double) /* running sums; the finished row is parked in the same slots */;
+}
+
+template <int KIND, int kRunWaves>
+__global__ __launch_bounds__(64 * kRunWaves) void perlin_grid_run_kernel(const PerlinGridArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char run_lds[];
+    const GridArgs &g = a.g;
+    const int depth = (KIND == kNoise) ? 1 : ((KIND == kFractal) ? 6 : a.depth);
+    // LDS carve-up (all 16-byte aligned)
+    RunKEntry *const ktab_all = reinterpret_cast<RunKEntry *>(run_lds);                        // [waves][64]
+    RunAxisEntry *const xtab = reinterpret_cast<RunAxisEntry *>(run_lds + kRunWaves * 64 * sizeof(RunKEntry)); // [depth][512]
+    RunAxisEntry *const ytab = xtab + (size_t)depth * kRunX;                                      // [depth][kRunTY]
+    RunAxisEntry *const ztab = ytab + (size_t)depth * kRunTY;                                     // [depth][kRunTZ]
+    int *const ycell = reinterpret_cast<int *>(ztab + (size_t)depth * kRunTZ);                    // [depth][kRunTY]
+    int *const zcell = ycell + depth * kRunTY;                                                    // [depth][kRunTZ]
+    uint8_t *const xcell = reinterpret_cast<uint8_t *>(zcell + depth * kRunTZ);                   // [depth][512]
+    uint8_t *const perm = xcell + (size_t)depth * kRunX;                                          // [512]
+    double *const acc_all = reinterpret_cast<double *>(run_lds + run_lds_bytes(depth, kRunWaves) - kRunWaves * kRun * 64 * sizeof(double));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x_first = blockIdx.x * kRunX, y_first = blockIdx.y * kRunTY, z_first = blockIdx.z * kRunTZ;
+    const float den = (float)g.den;
+
+    // ---- per-axis tables of the block ---------------------------------------------------------
+    for (int i = tid; i < 128; i += 64 * kRunWaves)
+        reinterpret_cast<uint32_t *>(perm)[i] = reinterpret_cast<const uint32_t *>(a.perm)[i];
+    // entry (axis, index): axis 0 = x (512 entries), 1 = y, 2 = z
+    auto tabulate = [&](float p, RunAxisEntry *tab, int stride_entries, int slot, int *cells32, uint8_t *cells8) {
+        float cur = p;         // turb: the float point doubles per octave
+        double frequency = 1.0; // fractal_noise: float point times a double frequency (perlin.h:82-84)
+        for (int i = 0; i < depth; ++i) {
+            const double c = (KIND == kFractal) ? (double)p * frequency : (double)cur;
+            const double fl = floor(c);
+            const int cell = (int)fl & 255;
+            const double f = c - fl;
+            tab[(size_t)i * stride_entries + slot] = RunAxisEntry{f, wn::pfade(f)};
+            if (cells32) cells32[i * stride_entries + slot] = cell;
+            else cells8[(size_t)i * stride_entries + slot] = (uint8_t)cell;
+            cur *= 2.0f;
+            frequency *= 2.0;
+        }
+    };
+    for (int xi = tid; xi < kRunX; xi += 64 * kRunWaves) {
+        const int x = min(x_first + xi, g.nx - 1);
+        tabulate(wn::lattice_coord(x, den, g.base_range, g.octave_scale, g.post_scale), xtab, kRunX, xi, nullptr, xcell);
+    }
+    if (tid < kRunTY) {
+        const int y = min(y_first + tid, g.ny - 1);
+        tabulate(wn::lattice_coord(y, den, g.base_range, g.octave_scale, g.post_scale), ytab, kRunTY, tid, ycell, nullptr);
+    } else if (tid >= 64 && tid < 64 + kRunTZ) {
+        const int zi = tid - 64;
+        const int z = g.z0 + min(z_first + zi, g.nz - 1);
+        const float pz = g.z_const_mode ? g.z_const : wn::lattice_coord(z, den, g.base_range, g.octave_scale, g.post_scale);
+        tabulate(pz, ztab, kRunTZ, zi, zcell, nullptr);
+    }
+    __syncthreads();
+
+    RunKEntry *const ktab = ktab_all + wave * 64;
+    const int rows_y = min(kRunTY, g.ny - y_first), rows_z = min(kRunTZ, g.nz - z_first);
+    // this lane's entry of the per-row table: hash h, corner (cy, cz)
+    const int kh = lane & 15, kcy = (lane >> 4) & 1, kcz = lane >> 5;
+    // [q][lane]: this wave's running sums (turb / fractal); a finished sample is parked as a float in the low
+    // half of its own slot, so no lane's pending sum is overwritten
+    double *const acc = acc_all + wave * (kRun * 64) + lane;
+    const float *const stage = reinterpret_cast<const float *>(acc_all + wave * (kRun * 64));
+    for (int r = wave; r < rows_y * rows_z; r += kRunWaves) {
+        const int yi = r % rows_y, zi = r / rows_y;
+        double amp_sum = 0.0, weight = 1.0; // turb weight / fractal amplitude
+
+        for (int oc = 0; oc < depth; ++oc) {
+            const RunAxisEntry ye = ytab[oc * kRunTY + yi], ze = ztab[oc * kRunTZ + zi];
+            const int Y = ycell[oc * kRunTY + yi], Z = zcell[oc * kRunTZ + zi];
+            // ---- per-row table: entry (cy, cz, h) -> {K, mm, t} (grad(), perlin.h:26-31) -------------
+            {
+                const double dy = kcy ? ye.f - 1.0 : ye.f, dz = kcz ? ze.f - 1.0 : ze.f;
+                const RunKEntry mine = wn::run_k_entry(kh, dy, dz);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the previous octave's reads are done
+                ktab[lane] = mine;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            const double v = ye.fade, w = ze.fade;
+            const RunAxisEntry *const xe = xtab + (size_t)oc * kRunX + lane * kRun;
+            // the run's 8 cell indices in one read
+            const uint64_t cells = *reinterpret_cast<const uint64_t *>(xcell + (size_t)oc * kRunX + lane * kRun);
+
+            double K[8];
+            uint32_t mm[8], tt[8];
+            int curX = -1;
+            // A rolled loop, two samples per trip (the whole run unrolled needs > 256 VGPRs); the x entries of
+            // the next trip are requested before this trip's arithmetic.
+            RunAxisEntry xa = xe[0], xb = xe[1];
+#pragma unroll 1
+            for (int q2 = 0; q2 < kRun; q2 += 2) {
+                const RunAxisEntry na = xe[min(q2 + 2, kRun - 2)], nb = xe[min(q2 + 3, kRun - 1)];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                const int q = q2 + s2;
+                const int X = (int)((cells >> (8 * q)) & 255u);
+                if (X != curX) { // the run entered a new cell: hash its 8 corners (perlin.h:55-61)
+                    curX = X;
+                    const int A = perm[X] + Y, AA = perm[A] + Z, AB = perm[A + 1] + Z;
+                    const int B = perm[X + 1] + Y, BA = perm[B] + Z, BB = perm[B + 1] + Z;
+                    const int h[8] = {perm[AA], perm[BA], perm[AB], perm[BB],
+                                      perm[AA + 1], perm[BA + 1], perm[AB + 1], perm[BB + 1]};
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const RunKEntry e = ktab[(c >> 1) * 16 + (h[c] & 15)];
+                        K[c] = e.K;
+                        mm[c] = e.mm;
+                        tt[c] = e.t;
+                    }
+                }
+                const RunAxisEntry x = s2 ? xb : xa;
+                const double xf = x.f, u = x.fade, xm1 = xf - 1.0;
+                const uint64_t b0 = (uint64_t)__double_as_longlong(xf), b1 = (uint64_t)__double_as_longlong(xm1);
+                double gr[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    gr[c] = wn::run_gradient(K[c], mm[c], tt[c], (c & 1) ? b1 : b0);
+                }
+                const double x00 = wn::plerp(u, gr[0], gr[1]), x10 = wn::plerp(u, gr[2], gr[3]);
+                const double x01 = wn::plerp(u, gr[4], gr[5]), x11 = wn::plerp(u, gr[6], gr[7]);
+                const double nv = wn::plerp(w, wn::plerp(v, x00, x10), wn::plerp(v, x01, x11));
+                double sum;
+                if (KIND == kNoise) sum = nv;
+                else {
+                    const double before = oc ? acc[q * 64] : 0.0;
+                    sum = (KIND == kTurb) ? before + weight * nv : before + nv * weight;
+                }
+                if (oc + 1 < depth) acc[q * 64] = sum;
+                else { // last octave: finish the sample and park it in the row stage
+                    if (KIND == kTurb) sum = fabs(sum);
+                    if (KIND == kFractal) sum = sum / (amp_sum + weight);
+                    *reinterpret_cast<float *>(acc + q * 64) = (float)sum * g.out_scale;
+                }
+                }
+                xa = na;
+                xb = nb;
+            }
+            if (KIND == kFractal) amp_sum += weight;
+            weight *= 0.5;
+        }
+
+        // the row leaves as contiguous 1-KiB wave stores
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float *const dst = a.out + ((size_t)(z_first + zi) * g.ny + (y_first + yi)) * g.nx + x_first;
+        typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int xo = half * 256 + lane * 4; // sample xo + e sits in slot (q, lane') = ((xo + e) % 8, (xo + e) / 8)
+            const float *const src = stage + 2 * ((((lane & 1) * 4) * 64) + (xo >> 3));
+            const v4f val = v4f{src[0], src[2 * 64], src[4 * 64], src[6 * 64]};
+            if (a.vec4_ok && x_first + xo + 4 <= g.nx) *reinterpret_cast<v4f *>(dst + xo) = val;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (x_first + xo + e < g.nx) dst[xo + e] = val[e];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the stage is read before the next row parks into it
     }
 }
 
@@ -193,10 +404,34 @@ int perlin_grid(const wn_perm *perm, const wn_grid *grid, int kind, int depth, f
     if (total == 0) return WN_OK;
     if (!out_dev) return wn::fail(WN_ERR_INVALID, "out_dev is NULL");
     if ((size_t)g.nx * g.ny > 0xffffffffull) return wn::fail(WN_ERR_INVALID, "plane too large");
-    PerlinGridArgs a{perm->dev, out_dev, g, kind, depth};
-    hipLaunchKernelGGL(perlin_grid_kernel, dim3(blocks_for(total)), dim3(256), 0,
+    PerlinGridArgs a{perm->dev, out_dev, g, kind, depth, 0};
+    a.vec4_ok = (g.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
+    const int octaves = kind == kNoise ? 1 : (kind == kFractal ? 6 : depth);
+    const dim3 rgrid((g.nx + kRunX - 1) / kRunX, (g.ny + kRunTY - 1) / kRunTY, (g.nz + kRunTZ - 1) / kRunTZ);
+    // the run kernel: rows of >= 128 samples (a lane owns 8 consecutive x samples), 1..8 octaves
+    if (g.nx >= 128 && octaves >= 1 && octaves <= kRunMaxDepth && rgrid.y <= 65535u && rgrid.z <= 65535u) {
+        const bool wide = octaves > 2; // 16 waves on one set of axis tables (see kRunWaves above)
+        const size_t lds = run_lds_bytes(octaves, wide ? 16 : 8);
+        const void *fn;
+        if (wide)
+            fn = kind == kNoise ? reinterpret_cast<const void *>(&perlin_grid_run_kernel<kNoise, 16>)
+                 : kind == kTurb ? reinterpret_cast<const void *>(&perlin_grid_run_kernel<kTurb, 16>)
+                                 : reinterpret_cast<const void *>(&perlin_grid_run_kernel<kFractal, 16>);
+        else
+            fn = kind == kNoise ? reinterpret_cast<const void *>(&perlin_grid_run_kernel<kNoise, 8>)
+                 : kind == kTurb ? reinterpret_cast<const void *>(&perlin_grid_run_kernel<kTurb, 8>)
+                                 : reinterpret_cast<const void *>(&perlin_grid_run_kernel<kFractal, 8>);
+        if (lds <= 48 * 1024 || wn::ensure_dynamic_lds(fn, wn::current_device(), run_lds_bytes(kRunMaxDepth, wide ? 16 : 8))) {
+            void *params[] = {&a};
+            const hipError_t e = hipLaunchKernel(fn, rgrid, dim3(wide ? 1024 : 512), params, lds, wn::as_stream(stream));
+            if (e != hipSuccess) return wn::hip_fail(e, "perlin_grid_run_kernel");
+            WN_LAUNCH_CHECK("perlin_grid_run_kernel");
+            return WN_OK;
+        }
+    }
+    hipLaunchKernelGGL(perlin_grid_generic_kernel, dim3(blocks_for(total)), dim3(256), 0,
                        wn::as_stream(stream), a);
-    WN_LAUNCH_CHECK("perlin_grid_kernel");
+    WN_LAUNCH_CHECK("perlin_grid_generic_kernel");
     return WN_OK;
 }
 
