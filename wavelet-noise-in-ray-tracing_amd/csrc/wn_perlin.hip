@@ -135,16 +135,20 @@ __global__ __launch_bounds__(64 * kRunWaves) void perlin_grid_run_kernel(const P
             const double fl = floor(c);
             const int cell = (int)fl & 255;
             const double f = c - fl;
-            tab[(size_t)i * stride_entries + slot] = RunAxisEntry{f, wn::pfade(f)};
+            if (tab) tab[(size_t)i * stride_entries + slot] = RunAxisEntry{f, wn::pfade(f)};
             if (cells32) cells32[i * stride_entries + slot] = cell;
-            else cells8[(size_t)i * stride_entries + slot] = (uint8_t)cell;
+            else if (cells8) cells8[(size_t)i * stride_entries + slot] = (uint8_t)cell;
             cur *= 2.0f;
             frequency *= 2.0;
         }
     };
+    // x entries are stored [octave][q][lane] (sample x = lane*8 + q): the 64 lanes of a wave read 64 adjacent
+    // 16-byte entries; [lane][q] order put all lanes on the same banks (8-way conflicts, 12 % of the kernel)
     for (int xi = tid; xi < kRunX; xi += 64 * kRunWaves) {
         const int x = min(x_first + xi, g.nx - 1);
-        tabulate(wn::lattice_coord(x, den, g.base_range, g.octave_scale, g.post_scale), xtab, kRunX, xi, nullptr, xcell);
+        const float px = wn::lattice_coord(x, den, g.base_range, g.octave_scale, g.post_scale);
+        tabulate(px, xtab, kRunX, (xi & (kRun - 1)) * 64 + (xi >> 3), nullptr, nullptr);
+        tabulate(px, nullptr, kRunX, xi, nullptr, xcell);
     }
     if (tid < kRunTY) {
         const int y = min(y_first + tid, g.ny - 1);
@@ -181,25 +185,21 @@ __global__ __launch_bounds__(64 * kRunWaves) void perlin_grid_run_kernel(const P
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
             const double v = ye.fade, w = ze.fade;
-            const RunAxisEntry *const xe = xtab + (size_t)oc * kRunX + lane * kRun;
+            const RunAxisEntry *const xe = xtab + (size_t)oc * kRunX + lane; // entry q at xe[q * 64]
             // the run's 8 cell indices in one read
             const uint64_t cells = *reinterpret_cast<const uint64_t *>(xcell + (size_t)oc * kRunX + lane * kRun);
 
-            double K[8];
-            uint32_t mm[8], tt[8];
-            int curX = -1;
-            // A rolled loop, two samples per trip (the whole run unrolled needs > 256 VGPRs); the x entries of
-            // the next trip are requested before this trip's arithmetic.
-            RunAxisEntry xa = xe[0], xb = xe[1];
-#pragma unroll 1
-            for (int q2 = 0; q2 < kRun; q2 += 2) {
-                const RunAxisEntry na = xe[min(q2 + 2, kRun - 2)], nb = xe[min(q2 + 3, kRun - 1)];
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                const int q = q2 + s2;
+            // Segments of the run that stay inside one cell (at the BASELINE lattice: the whole run).  Both loops
+            // are rolled and q is a per-lane value -- everything indexed by q lives in LDS -- so the corner state
+            // K / mm / tt is defined once per segment and never copied between branches (the unrolled form with a
+            // conditional re-hash per sample spent a third of its instructions on such copies).
+            int q = 0;
+            while (q < kRun) {
                 const int X = (int)((cells >> (8 * q)) & 255u);
-                if (X != curX) { // the run entered a new cell: hash its 8 corners (perlin.h:55-61)
-                    curX = X;
+                // the segment's cell: hash its 8 corners (perlin.h:55-61) and fetch their {K, mm, t}
+                double K[8];
+                uint32_t mm[8], tt[8];
+                {
                     const int A = perm[X] + Y, AA = perm[A] + Z, AB = perm[A + 1] + Z;
                     const int B = perm[X + 1] + Y, BA = perm[B] + Z, BB = perm[B + 1] + Z;
                     const int h[8] = {perm[AA], perm[BA], perm[AB], perm[BB],
@@ -212,32 +212,39 @@ __global__ __launch_bounds__(64 * kRunWaves) void perlin_grid_run_kernel(const P
                         tt[c] = e.t;
                     }
                 }
-                const RunAxisEntry x = s2 ? xb : xa;
-                const double xf = x.f, u = x.fade, xm1 = xf - 1.0;
-                const uint64_t b0 = (uint64_t)__double_as_longlong(xf), b1 = (uint64_t)__double_as_longlong(xm1);
-                double gr[8];
+                auto sample = [&](int qs, const RunAxisEntry &x) {
+                    const double xf = x.f, u = x.fade, xm1 = xf - 1.0;
+                    const uint64_t b0 = (uint64_t)__double_as_longlong(xf), b1 = (uint64_t)__double_as_longlong(xm1);
+                    double gr[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    gr[c] = wn::run_gradient(K[c], mm[c], tt[c], (c & 1) ? b1 : b0);
-                }
-                const double x00 = wn::plerp(u, gr[0], gr[1]), x10 = wn::plerp(u, gr[2], gr[3]);
-                const double x01 = wn::plerp(u, gr[4], gr[5]), x11 = wn::plerp(u, gr[6], gr[7]);
-                const double nv = wn::plerp(w, wn::plerp(v, x00, x10), wn::plerp(v, x01, x11));
-                double sum;
-                if (KIND == kNoise) sum = nv;
-                else {
-                    const double before = oc ? acc[q * 64] : 0.0;
-                    sum = (KIND == kTurb) ? before + weight * nv : before + nv * weight;
-                }
-                if (oc + 1 < depth) acc[q * 64] = sum;
-                else { // last octave: finish the sample and park it in the row stage
-                    if (KIND == kTurb) sum = fabs(sum);
-                    if (KIND == kFractal) sum = sum / (amp_sum + weight);
-                    *reinterpret_cast<float *>(acc + q * 64) = (float)sum * g.out_scale;
-                }
-                }
-                xa = na;
-                xb = nb;
+                    for (int c = 0; c < 8; ++c) gr[c] = wn::run_gradient(K[c], mm[c], tt[c], (c & 1) ? b1 : b0);
+                    const double x00 = wn::plerp(u, gr[0], gr[1]), x10 = wn::plerp(u, gr[2], gr[3]);
+                    const double x01 = wn::plerp(u, gr[4], gr[5]), x11 = wn::plerp(u, gr[6], gr[7]);
+                    const double nv = wn::plerp(w, wn::plerp(v, x00, x10), wn::plerp(v, x01, x11));
+                    double sum;
+                    if (KIND == kNoise) sum = nv;
+                    else {
+                        const double before = oc ? acc[qs * 64] : 0.0;
+                        sum = (KIND == kTurb) ? before + weight * nv : before + nv * weight;
+                    }
+                    if (oc + 1 < depth) acc[qs * 64] = sum;
+                    else { // last octave: finish the sample and park it in its own slot
+                        if (KIND == kTurb) sum = fabs(sum);
+                        if (KIND == kFractal) sum = sum / (amp_sum + weight);
+                        *reinterpret_cast<float *>(acc + qs * 64) = (float)sum * g.out_scale;
+                    }
+                };
+                auto cell_at = [&](int qq) { return (int)((cells >> (8 * qq)) & 255u); };
+                RunAxisEntry x = xe[q * 64];
+                bool more;
+                do { // one sample per trip; two per trip (more ILP, half the loop control) measured the same
+                    const int q1 = min(q + 1, kRun - 1);
+                    const RunAxisEntry xnext = xe[q1 * 64]; // requested before this sample's arithmetic
+                    sample(q, x);
+                    ++q;
+                    more = q < kRun && cell_at(q1) == X;
+                    x = xnext;
+                } while (more);
             }
             if (KIND == kFractal) amp_sum += weight;
             weight *= 0.5;

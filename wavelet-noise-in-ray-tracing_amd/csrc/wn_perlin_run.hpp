@@ -46,15 +46,18 @@ WN_HD double run_gradient(double K, uint32_t mm, uint32_t t, uint64_t dx_bits)
     const uint32_t lo = (uint32_t)dx_bits & mm;
 #if defined(__HIP_DEVICE_COMPILE__)
     // (hi & mm) ^ t as ONE v_bitop3_b32 (truth table index = S0<<2 | S1<<1 | S2 -> 0x6a); written as plain
-    // C the optimiser splits the xor into sign and magnitude halves: four instructions instead of one
+    // C the optimiser splits the xor into sign and magnitude halves: four instructions instead of one.
+    // The halves are joined with __hiloint2double: a 64-bit shift-and-or leaves a byte-wise re-assembly
+    // (v_and 0xffffff00 + v_or_b32_sdwa) of the high dword behind.
     const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(dx_bits >> 32), mm, t, 0x6a);
+    return __hiloint2double((int)hi, (int)lo) + K;
 #else
     const uint32_t hi = ((uint32_t)(dx_bits >> 32) & mm) ^ t;
-#endif
     const uint64_t b = ((uint64_t)hi << 32) | lo;
     double a;
     memcpy(&a, &b, sizeof(a));
     return a + K;
+#endif
 }
 
 } // namespace wn
