@@ -548,14 +548,20 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
               const float *weights, float out_div, SepArgs *a, size_t *lds_bytes)
 {
     // two wave columns (512-sample bricks: whole 2-KiB rows written together) when the lattice is wide
-    const int xw = g.nx > 256 ? 2 : 1;
+    int xw = g.nx > 256 ? 2 : 1;
+#ifdef WN_TUNE_ENV
+    if (const char *e = getenv("WN_SEP_XW")) xw = atoi(e);
+#endif
     const int kBrickX = 256 * xw;
     a->xw = xw;
     if (tile->n == 0 || nbands < 1 || nbands > kMaxBands) return false;
     if (pow2_mask(tile->n) < 0) return false; // the brick kernel wraps with a mask: power-of-two tiles
     if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0) return false;
     if (!g.z_const_mode && g.z0 < 0) return false; // negative plane indices: the exact kernel (bounds below assume indices >= 0)
-    const int BZ = g.nz >= kMaxBZ ? kMaxBZ : ceil_pow2(g.nz);
+    int BZ = g.nz >= kMaxBZ ? kMaxBZ : ceil_pow2(g.nz);
+#ifdef WN_TUNE_ENV
+    if (const char *e = getenv("WN_SEP_BZ")) BZ = std::min(BZ, atoi(e));
+#endif
     const int rows = kBrickY * BZ;
     const double zmax = g.z_const_mode ? 0.0 : (double)g.z0 + g.nz;
     const double imax = fmax(fmax((double)g.nx, (double)g.ny), zmax);
@@ -604,14 +610,21 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
     return true;
 }
 
-// Persistent grid: k workgroups per CU, k chosen (within what LDS and the 32-wave limit admit)
-// so that the bricks divide as evenly as possible over the workgroups.
-int persistent_grid(long long items, size_t lds_bytes, int xw)
+// Persistent grid.  Single band: ONE workgroup per CU -- measured on MI355X (profiles/r02_sep_knob_sweep.txt):
+// 2048 x 2048 x 256 slab 748 us with 1 workgroup per CU against 777-787 with 2-3, 1024^3 803 against 853-866; the
+// double-buffered one-barrier pipeline already overlaps a brick's loads, collapse and stores inside one
+// workgroup, and a second resident workgroup only adds contention on the store path.  Several bands: k workgroups
+// per CU, k chosen (within what LDS and the 32-wave limit admit) so that the bricks divide evenly.
+int persistent_grid(long long items, size_t lds_bytes, int xw, int nbands)
 {
     const int cus = wn::device_compute_units(wn::current_device());
     int kmax = (int)((160 * 1024) / (lds_bytes + 2048));
     const int wave_cap = 8 / xw; // 32 waves per CU
     kmax = kmax > wave_cap ? wave_cap : (kmax < 1 ? 1 : kmax);
+#ifdef WN_TUNE_ENV
+    if (const char *e = getenv("WN_SEP_K")) return (int)std::min<long long>(items, (long long)cus * std::min(kmax, atoi(e)));
+#endif
+    if (nbands == 1) return (int)std::min<long long>(items, cus);
     int best_k = kmax;
     double best_eff = -1.0;
     for (int k = kmax; k >= (kmax > 4 ? 4 : 1); --k) {
@@ -632,7 +645,7 @@ bool launch_sep2(const SepArgs &a, size_t lds, hipStream_t s)
     if (lds > 48 * 1024 &&
         !wn::ensure_dynamic_lds(reinterpret_cast<const void *>(&grid3d_sep_kernel<NB, XW>), wn::current_device(), 128 * 1024))
         return false;
-    hipLaunchKernelGGL((grid3d_sep_kernel<NB, XW>), dim3(persistent_grid(items, lds, XW)),
+    hipLaunchKernelGGL((grid3d_sep_kernel<NB, XW>), dim3(persistent_grid(items, lds, XW, NB)),
                        dim3(256 * XW), lds, s, a);
     return true;
 }
