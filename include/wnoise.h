@@ -204,6 +204,29 @@ WN_API int wn_noise_texture_points(const wn_perm *perm, double scale, int octave
                                    const float *xyz_dev, const uint8_t *active_dev, size_t n,
                                    float *grey_dev, void *stream);
 
+/* ---- scalar calls: the reference's scalar members, one value per call ------------------------------
+ * evaluate2D/3D/3DProjected(p) (WaveletNoise.h:32-35), noise(x,y,z) / noise(point3) / fractal_noise(p)
+ * (perlin.h:42-90), texture::value(u,v,p) (texture.h:17) as the reference's callers use them
+ * (material.h:72, experient/main.cpp:28,56,85,104,122).  A kernel launch per call costs ~22 us; these
+ * entry points hand the request to a resident one-wave kernel through a mailbox in pinned host memory
+ * (csrc/wn_mailbox.hip): a few microseconds per call, results bit-identical to the batched entry points.
+ * They block until the value is back and are serialised across host threads.  The resident kernel ends
+ * by itself after 2 ms without a request (a device-wide synchronise never waits longer) and is restarted
+ * by the next call. */
+WN_API int wn_scalar_eval3d(const wn_tile *tile3d, const float p[3], float *out);
+WN_API int wn_scalar_eval2d(const wn_tile *tile2d, const float p[2], float *out);
+WN_API int wn_scalar_eval3d_projected(const wn_tile *tile3d, const float p[3], const float normal[3],
+                                      float *out);
+WN_API int wn_scalar_perlin(const wn_perm *perm, double x, double y, double z, double *out);
+/* kind 0: noise(const point3&), 1: turb(p, depth) (RTOW), 2: fractal_noise(p). */
+WN_API int wn_scalar_perlin_vec3(const wn_perm *perm, const float p[3], int kind, int depth, double *out);
+WN_API int wn_scalar_wavelet_texture(const wn_tile *tile, int use_3d, double scale, int octave,
+                                     const float p[3], float *grey);
+WN_API int wn_scalar_noise_texture(const wn_perm *perm, double scale, int octave, const float p[3],
+                                   float *grey);
+/* Scalar calls served so far and resident-kernel instances started for them (diagnostics). */
+WN_API int wn_scalar_stats(unsigned long long *calls, unsigned long long *launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,14 @@ SIGNATURES = {
     "wn_perlin_fractal_points": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "wn_wavelet_texture_points": (_i, [_vp, _i, _d, _i, _vp, _vp, _sz, _vp, _vp]),
     "wn_noise_texture_points": (_i, [_vp, _d, _i, _vp, _vp, _sz, _vp, _vp]),
+    "wn_scalar_eval3d": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "wn_scalar_eval2d": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "wn_scalar_eval3d_projected": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "wn_scalar_perlin": (_i, [_vp, _d, _d, _d, C.POINTER(C.c_double)]),
+    "wn_scalar_perlin_vec3": (_i, [_vp, C.POINTER(C.c_float), _i, _i, C.POINTER(C.c_double)]),
+    "wn_scalar_wavelet_texture": (_i, [_vp, _i, _d, _i, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "wn_scalar_noise_texture": (_i, [_vp, _d, _i, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "wn_scalar_stats": (_i, [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
 }
 
 _lib = None

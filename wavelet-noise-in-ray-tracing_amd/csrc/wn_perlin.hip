@@ -10,6 +10,7 @@
 #include "wn_internal.hpp"
 #include "wn_device_eval.hpp"
 #include "wn_perlin_run.hpp"
+#include "wn_texture_eval.hpp"
 
 #include <cmath>
 
@@ -312,15 +313,10 @@ struct NoiseTexArgs {
     int points_per_wave;
 };
 
-__device__ __forceinline__ float noise_texture_value(const uint8_t *perm, const NoiseTexArgs &a,
-                                                     float px, float py, float pz)
+__device__ __forceinline__ float noise_texture_value(const uint8_t *perm, const NoiseTexArgs &a, float px, float py,
+                                                     float pz)
 {
-    const float sx = (a.fscale * px) * a.octave_scale;
-    const float sy = (a.fscale * py) * a.octave_scale;
-    const float sz = (a.fscale * pz) * a.octave_scale;
-    double v = wn::perlin_exact(perm, (double)sx, (double)sy, (double)sz);
-    v = 0.5 * (1.0 + v);
-    return (float)v;
+    return wn::noise_texture_value(perm, a.fscale, a.octave_scale, px, py, pz); // wn_texture_eval.hpp
 }
 
 template <bool MASKED>

@@ -9,6 +9,7 @@
 // batches, so rays that missed the noise-textured surfaces cost no gather slots.
 #include "wn_internal.hpp"
 #include "wn_device_eval.hpp"
+#include "wn_texture_eval.hpp"
 
 #include <cmath>
 
@@ -92,32 +93,7 @@ struct TexArgs {
     int points_per_wave;
 };
 
-template <bool PADDED>
-__device__ __forceinline__ float wavelet_texture_value(const TexArgs &a, float px, float py,
-                                                       float pz)
-{
-    double v;
-    if (a.mode == 3) {
-        float pos[3] = {(float)((double)px * a.scale), (float)((double)py * a.scale),
-                        (float)((double)pz * a.scale)};
-        pos[0] *= a.octave_mul;
-        pos[1] *= a.octave_mul;
-        pos[2] *= a.octave_mul;
-        v = (double)wn::eval3d_exact<PADDED>(a.coef, a.n, a.nmask, pos[0], pos[1], pos[2]);
-        v *= (double)a.inv_stddev;
-    } else if (a.mode == 2) {
-        float pos[2] = {(float)((double)px * a.scale), (float)((double)py * a.scale)};
-        pos[0] *= a.octave_mul;
-        pos[1] *= a.octave_mul;
-        v = (double)wn::eval2d_exact(a.coef, a.n, a.nmask, pos[0], pos[1]);
-        v *= (double)a.inv_stddev;
-    } else {
-        v = 0.0;
-    }
-    const double q = v / 4.0;
-    const double c = (q < -1.0) ? -1.0 : ((1.0 < q) ? 1.0 : q); // std::clamp
-    return (float)(0.5 * (1.0 + c));                              // texture.h:104-106
-}
+using wn::wavelet_texture_value; // wn_texture_eval.hpp
 
 template <bool MASKED, bool PADDED>
 __global__ __launch_bounds__(256) void wavelet_texture_kernel(const TexArgs a)

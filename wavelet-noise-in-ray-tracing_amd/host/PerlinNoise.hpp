@@ -25,14 +25,9 @@ class PerlinNoise {
 
     double noise(double x, double y, double z) const // PerlinNoise.hpp:36-56
     {
-        auto &s = wnhost::Scratch::get();
-        s.in_host64()[0] = x;
-        s.in_host64()[1] = y;
-        s.in_host64()[2] = z;
-        wnhost::check(wn_perlin_points(perm_, static_cast<const double *>(s.in_dev()), 1,
-                                       static_cast<double *>(s.out_dev()), nullptr), "wn_perlin_points");
-        wnhost::check(wn_stream_sync(nullptr), "wn_stream_sync");
-        return s.out_host64()[0];
+        double v = 0.0;
+        wnhost::check(wn_scalar_perlin(perm_, x, y, z, &v), "wn_scalar_perlin");
+        return v;
     }
     double noise(double x, double y) const { return noise(x, y, 0.0); } // PerlinNoise.hpp:58-60
 

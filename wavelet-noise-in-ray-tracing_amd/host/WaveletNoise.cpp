@@ -42,38 +42,26 @@ const wn_tile *WaveletNoise::tile(int dims) const
     return tile_;
 }
 
-// ---- scalar members: a batch of one through the mapped scratch ------------------------------------
+// ---- scalar members: one request each to the resident scalar kernel (wn_scalar_*, include/wnoise.h) ---
 float WaveletNoise::evaluate2D(const float p[2]) const
 {
-    auto &s = wnhost::Scratch::get();
-    s.in_host()[0] = p[0];
-    s.in_host()[1] = p[1];
-    check(wn_eval2d_points(tile(2), static_cast<const float *>(s.in_dev()), 1,
-                           static_cast<float *>(s.out_dev()), nullptr), "wn_eval2d_points");
-    check(wn_stream_sync(nullptr), "wn_stream_sync");
-    return s.out_host()[0];
+    float v = 0.0f;
+    check(wn_scalar_eval2d(tile(2), p, &v), "wn_scalar_eval2d");
+    return v;
 }
 
 float WaveletNoise::evaluate3D(const float p[3]) const
 {
-    auto &s = wnhost::Scratch::get();
-    std::copy(p, p + 3, s.in_host());
-    check(wn_eval3d_points(tile(3), static_cast<const float *>(s.in_dev()), 1,
-                           static_cast<float *>(s.out_dev()), nullptr), "wn_eval3d_points");
-    check(wn_stream_sync(nullptr), "wn_stream_sync");
-    return s.out_host()[0];
+    float v = 0.0f;
+    check(wn_scalar_eval3d(tile(3), p, &v), "wn_scalar_eval3d");
+    return v;
 }
 
 float WaveletNoise::evaluate3DProjected(const float p[3], const float normal[3]) const
 {
-    auto &s = wnhost::Scratch::get();
-    std::copy(p, p + 3, s.in_host());
-    std::copy(normal, normal + 3, s.in_host() + 4);
-    const float *in = static_cast<const float *>(s.in_dev());
-    check(wn_eval3d_projected_points(tile(3), in, in + 4, 1, static_cast<float *>(s.out_dev()), nullptr),
-          "wn_eval3d_projected_points");
-    check(wn_stream_sync(nullptr), "wn_stream_sync");
-    return s.out_host()[0];
+    float v = 0.0f;
+    check(wn_scalar_eval3d_projected(tile(3), p, normal, &v), "wn_scalar_eval3d_projected");
+    return v;
 }
 
 float WaveletNoise::WMultibandNoise(const float p[3], float sarg, int firstBand, int nbands,

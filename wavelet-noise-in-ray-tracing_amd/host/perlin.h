@@ -22,13 +22,12 @@ class perlin {
     std::vector<int> p; // host mirror of the table (perlin.h:16)
     wn_perm *perm_ = nullptr;
 
-    template <typename Launch> double scalar(const float xyz[3], Launch launch) const
+    double scalar(const point3 &q, int kind, int depth) const // one request to the resident scalar kernel
     {
-        auto &s = wnhost::Scratch::get();
-        for (int i = 0; i < 3; ++i) s.in_host()[i] = xyz[i];
-        launch(static_cast<const float *>(s.in_dev()), static_cast<double *>(s.out_dev()));
-        wnhost::check(wn_stream_sync(nullptr), "wn_stream_sync");
-        return s.out_host64()[0];
+        const float xyz[3] = {q.x(), q.y(), q.z()};
+        double v = 0.0;
+        wnhost::check(wn_scalar_perlin_vec3(perm_, xyz, kind, depth, &v), "wn_scalar_perlin_vec3");
+        return v;
     }
 
   public:
@@ -44,32 +43,21 @@ class perlin {
     // perlin.h:42-62
     double noise(double x, double y, double z) const noexcept(false)
     {
-        auto &s = wnhost::Scratch::get();
-        s.in_host64()[0] = x;
-        s.in_host64()[1] = y;
-        s.in_host64()[2] = z;
-        wnhost::check(wn_perlin_points(perm_, static_cast<const double *>(s.in_dev()), 1,
-                                       static_cast<double *>(s.out_dev()), nullptr), "wn_perlin_points");
-        wnhost::check(wn_stream_sync(nullptr), "wn_stream_sync");
-        return s.out_host64()[0];
+        double v = 0.0;
+        wnhost::check(wn_scalar_perlin(perm_, x, y, z, &v), "wn_scalar_perlin");
+        return v;
     }
     double noise(double x, double y) const { return noise(x, y, 0.0); }              // perlin.h:65-67
     double noise(const point3 &q) const { return noise(q.x(), q.y(), q.z()); }        // perlin.h:70-72
 
     double fractal_noise(const point3 &q) const                                       // perlin.h:75-90
     {
-        const float xyz[3] = {q.x(), q.y(), q.z()};
-        return scalar(xyz, [&](const float *in, double *out) {
-            wnhost::check(wn_perlin_fractal_points(perm_, in, 1, out, nullptr), "wn_perlin_fractal_points");
-        });
+        return scalar(q, 2, 0);
     }
     // RTOW "The Next Week" turb(p, depth); absent from the reference.
     double turb(const point3 &q, int depth = 7) const
     {
-        const float xyz[3] = {q.x(), q.y(), q.z()};
-        return scalar(xyz, [&](const float *in, double *out) {
-            wnhost::check(wn_perlin_turb_points(perm_, in, 1, depth, out, nullptr), "wn_perlin_turb_points");
-        });
+        return scalar(q, 1, depth);
     }
 
     // ---- additive: batched forms (host pointers) and the device-resident table -------------------

@@ -63,16 +63,9 @@ class noise_texture : public texture {
 
     color value(double, double, const point3 &p) const override // texture.h:37-43
     {
-        auto &s = wnhost::Scratch::get();
-        s.in_host()[0] = p.x();
-        s.in_host()[1] = p.y();
-        s.in_host()[2] = p.z();
-        wnhost::check(wn_noise_texture_points(noise.perm(), scale, octave_level,
-                                              static_cast<const float *>(s.in_dev()), nullptr, 1,
-                                              static_cast<float *>(s.out_dev()), nullptr),
-                      "wn_noise_texture_points");
-        wnhost::check(wn_stream_sync(nullptr), "wn_stream_sync");
-        const float g = s.out_host()[0];
+        const float xyz[3] = {p.x(), p.y(), p.z()};
+        float g = 0.0f; // one request to the resident scalar kernel (include/wnoise.h, wn_scalar_*)
+        wnhost::check(wn_scalar_noise_texture(noise.perm(), scale, octave_level, xyz, &g), "wn_scalar_noise_texture");
         return color(g, g, g);
     }
     // additive: batched grey levels (host pointers); active == nullptr means every point
@@ -107,17 +100,11 @@ class wavelet_texture : public texture {
 
     color value(double, double, const point3 &p) const override // texture.h:67-107
     {
-        auto &s = wnhost::Scratch::get();
-        s.in_host()[0] = p.x();
-        s.in_host()[1] = p.y();
-        s.in_host()[2] = p.z();
+        const float xyz[3] = {p.x(), p.y(), p.z()};
         const bool three = use_3d_noise && noise_3d;
-        wnhost::check(wn_wavelet_texture_points(source(three), three ? 1 : 0, scale, octave_level,
-                                                static_cast<const float *>(s.in_dev()), nullptr, 1,
-                                                static_cast<float *>(s.out_dev()), nullptr),
-                      "wn_wavelet_texture_points");
-        wnhost::check(wn_stream_sync(nullptr), "wn_stream_sync");
-        const float g = s.out_host()[0];
+        float g = 0.0f;
+        wnhost::check(wn_scalar_wavelet_texture(source(three), three ? 1 : 0, scale, octave_level, xyz, &g),
+                      "wn_scalar_wavelet_texture");
         return color(g, g, g);
     }
     void values(const float *xyz, const uint8_t *active, size_t n, float *grey) const

@@ -152,6 +152,17 @@ class WaveletNoise:
         return self.tileSizeN
 
     # -- evaluation: a single point returns a float, an (N,k) batch returns a CUDA tensor
+    def _scalar(self, fn, dims, p, width, normal=None):
+        """One value through the resident scalar kernel (wn_scalar_*: no launch per call)."""
+        a = (C.c_float * width)(*[float(v) for v in (p.tolist() if hasattr(p, "tolist") else p)])
+        out = C.c_float(0)
+        if normal is None:
+            check(fn(self._handle(dims), a, C.byref(out)))
+        else:
+            nr = (C.c_float * 3)(*[float(v) for v in (normal.tolist() if hasattr(normal, "tolist") else normal)])
+            check(fn(self._handle(dims), a, nr, C.byref(out)))
+        return out.value
+
     def _points(self, fn, dims, p, width, extra=None):
         single = _is_scalar_point(p, width)
         pts = _dev(p, torch.float32).reshape(-1, width)
@@ -163,12 +174,18 @@ class WaveletNoise:
         return float(out.item()) if single else out
 
     def evaluate2D(self, p):
+        if _is_scalar_point(p, 2):
+            return self._scalar(_lib.wn_scalar_eval2d, 2, p, 2)
         return self._points(_lib.wn_eval2d_points, 2, p, 2)
 
     def evaluate3D(self, p):
+        if _is_scalar_point(p, 3):
+            return self._scalar(_lib.wn_scalar_eval3d, 3, p, 3)
         return self._points(_lib.wn_eval3d_points, 3, p, 3)
 
     def evaluate3DProjected(self, p, normal):
+        if _is_scalar_point(p, 3) and _is_scalar_point(normal, 3):
+            return self._scalar(_lib.wn_scalar_eval3d_projected, 3, p, 3, normal)
         pts = _dev(p, torch.float32).reshape(-1, 3)
         nr = _dev(normal, torch.float32).reshape(-1, 3)
         if nr.shape[0] == 1 and pts.shape[0] != 1:
@@ -222,25 +239,38 @@ class perlin:
         (N,3) batch: float32 input follows noise(const point3&) (perlin.h:70), float64 input
         follows noise(double,double,double)."""
         if y is not None:
-            pts = _dev([[float(x), float(y), 0.0 if z is None else float(z)]], torch.float64)
-            return float(self._run(_lib.wn_perlin_points, pts).item())
+            out = C.c_double(0)
+            check(_lib.wn_scalar_perlin(self._h, float(x), float(y), 0.0 if z is None else float(z), C.byref(out)))
+            return out.value
         single = _is_scalar_point(x, 3)
         is64 = (x.dtype == torch.float64) if isinstance(x, torch.Tensor) else \
             (np.asarray(x).dtype == np.float64 and not single)
+        if single and not is64:
+            return self._scalar_vec3(x, 0)  # noise(const point3&), perlin.h:70
         if is64:
             out = self._run(_lib.wn_perlin_points, _dev(x, torch.float64).reshape(-1, 3))
         else:
             out = self._run(_lib.wn_perlin_points_vec3, _dev(x, torch.float32).reshape(-1, 3))
         return float(out.item()) if single else out
 
+    def _scalar_vec3(self, p, kind, depth=0):
+        a = (C.c_float * 3)(*[float(v) for v in (p.tolist() if hasattr(p, "tolist") else p)])
+        out = C.c_double(0)
+        check(_lib.wn_scalar_perlin_vec3(self._h, a, kind, depth, C.byref(out)))
+        return out.value
+
     def fractal_noise(self, p):
         single = _is_scalar_point(p, 3)
+        if single:
+            return self._scalar_vec3(p, 2)
         out = self._run(_lib.wn_perlin_fractal_points, _dev(p, torch.float32).reshape(-1, 3))
         return float(out.item()) if single else out
 
     def turb(self, p, depth=7):
         """RTOW turb(p, depth); absent from the reference."""
         single = _is_scalar_point(p, 3)
+        if single:
+            return self._scalar_vec3(p, 1, int(depth))
         out = self._run(_lib.wn_perlin_turb_points, _dev(p, torch.float32).reshape(-1, 3), int(depth))
         return float(out.item()) if single else out
 
@@ -264,10 +294,12 @@ class noise_texture:
         return out
 
     def value(self, u, v, p):
+        if _is_scalar_point(p, 3):  # the reference's call shape: one request to the resident scalar kernel
+            a = (C.c_float * 3)(*[float(x) for x in (p.tolist() if hasattr(p, "tolist") else p)])
+            out = C.c_float(0)
+            check(_lib.wn_scalar_noise_texture(self.noise._h, self.scale, self.octave_level, a, C.byref(out)))
+            return (out.value,) * 3
         g = self.grey(p)
-        if _is_scalar_point(p, 3):
-            g = float(g.item())
-            return (g, g, g)
         return g[:, None].expand(-1, 3)
 
 
@@ -295,10 +327,15 @@ class wavelet_texture:
         return out
 
     def value(self, u, v, p):
-        g = self.grey(p)
         if _is_scalar_point(p, 3):
-            g = float(g.item())
-            return (g, g, g)
+            use3d = self.use_3d_noise and self.noise_3d is not None
+            src = self.noise_3d if use3d else self.noise_2d
+            a = (C.c_float * 3)(*[float(x) for x in (p.tolist() if hasattr(p, "tolist") else p)])
+            out = C.c_float(0)
+            check(_lib.wn_scalar_wavelet_texture(src._handle(3 if use3d else 2), int(use3d), self.scale,
+                                                 self.octave_level, a, C.byref(out)))
+            return (out.value,) * 3
+        g = self.grey(p)
         return g[:, None].expand(-1, 3)
 
 
