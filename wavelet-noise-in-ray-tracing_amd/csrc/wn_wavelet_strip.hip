@@ -39,6 +39,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #ifdef WN_STRIP_STAMPS
 #include <cstdio>
 #endif
@@ -371,6 +372,9 @@ namespace wn {
 int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_t stream, bool *launched)
 {
     *launched = false;
+#ifdef WN_TUNE_ENV
+    if (getenv("WN_NO_STRIP")) return WN_OK;
+#endif
     if (tile->n < 4 || pow2_mask(tile->n) < 0) return WN_OK;
     if (g.z_const_mode || g.nx <= 0 || g.ny <= 0 || g.nz <= 0) return WN_OK;
     if (g.z0 < 0) return WN_OK; // negative plane indices: the exact kernel (the bounds below assume indices >= 0)

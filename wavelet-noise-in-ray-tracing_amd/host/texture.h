@@ -76,6 +76,12 @@ class noise_texture : public texture {
                           "wn_noise_texture_points");
         });
     }
+    // additive: device pointers, enqueue only (default stream)
+    void values_device(const float *xyz_dev, size_t n, float *grey_dev) const
+    {
+        wnhost::check(wn_noise_texture_points(noise.perm(), scale, octave_level, xyz_dev, nullptr, n, grey_dev, nullptr),
+                      "wn_noise_texture_points");
+    }
 
   private:
     perlin noise; // default seed, texture.h:46
@@ -114,6 +120,13 @@ class wavelet_texture : public texture {
             wnhost::check(wn_wavelet_texture_points(source(three), three ? 1 : 0, scale, octave_level, in,
                                                     act, n, out, nullptr), "wn_wavelet_texture_points");
         });
+    }
+    // additive: device pointers, enqueue only (default stream)
+    void values_device(const float *xyz_dev, size_t n, float *grey_dev) const
+    {
+        const bool three = use_3d_noise && noise_3d;
+        wnhost::check(wn_wavelet_texture_points(source(three), three ? 1 : 0, scale, octave_level, xyz_dev, nullptr, n,
+                                                grey_dev, nullptr), "wn_wavelet_texture_points");
     }
 
   private:

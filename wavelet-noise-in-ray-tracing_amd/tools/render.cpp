@@ -20,6 +20,8 @@
 //   render [--width W] [--height H] [--spp S] [--noise 0|1] [--octave O] [--band-lines L]
 //          [--out file.ppm] [--rgb file.rgb] [--dry-run]
 //   --dry-run: no GPU; prints the count and FNV-1a64 of the hit-point stream (oracle/_ref check)
+//   --time-kernel: also times the texture kernel ALONE on every band's hit-point stream (points resident in
+//                  HBM, HIP events, best of 3 launches): the device rate on the renderer's real stream
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -187,7 +189,7 @@ struct Fnv {
 struct Options {
     int width = 1000, height = 500, spp = 100, noise = 1, octave = 4, band_lines = 25;
     std::string out_ppm, out_rgb;
-    bool dry_run = false;
+    bool dry_run = false, time_kernel = false;
 };
 
 } // namespace
@@ -206,6 +208,7 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--out")) opt.out_ppm = next();
         else if (!std::strcmp(argv[i], "--rgb")) opt.out_rgb = next();
         else if (!std::strcmp(argv[i], "--dry-run")) opt.dry_run = true;
+        else if (!std::strcmp(argv[i], "--time-kernel")) opt.time_kernel = true;
         else { std::fprintf(stderr, "render: unknown option %s\n", argv[i]); return 2; }
     }
     const int width = opt.width, height = opt.height, spp = opt.spp;
@@ -221,7 +224,7 @@ int main(int argc, char **argv)
         }
         std::vector<unsigned char> image((size_t)width * height * 3);
         Fnv stream;
-        double t_trace = 0, t_noise = 0;
+        double t_trace = 0, t_noise = 0, t_kernel = 0;
         size_t total_points = 0;
 
         // per band of scanlines: recorded bounces and per-sample bookkeeping
@@ -281,6 +284,24 @@ int main(int argc, char **argv)
             else perlin_tex->values(pts.data(), nullptr, npts, grey.data());
             auto t2 = std::chrono::steady_clock::now();
             t_noise += std::chrono::duration<double>(t2 - t1).count();
+            if (opt.time_kernel && npts) {
+                wnhost::DeviceBuffer in(3 * npts * sizeof(float)), out(npts * sizeof(float));
+                in.upload(pts.data());
+                wn_timer *tm = nullptr;
+                wnhost::check(wn_timer_create(&tm), "wn_timer_create");
+                float best = 1e30f;
+                for (int rep = 0; rep < 4; ++rep) { // the first launch warms the caches
+                    wnhost::check(wn_timer_start(tm, nullptr), "wn_timer_start");
+                    if (wavelet) wavelet->values_device(in.as<float>(), npts, out.as<float>());
+                    else perlin_tex->values_device(in.as<float>(), npts, out.as<float>());
+                    wnhost::check(wn_timer_stop(tm, nullptr), "wn_timer_stop");
+                    float ms = 0;
+                    wnhost::check(wn_timer_elapsed_ms(tm, &ms), "wn_timer_elapsed_ms");
+                    if (rep) best = std::min(best, ms);
+                }
+                wn_timer_destroy(tm);
+                t_kernel += best * 1e-3;
+            }
 
             // ---- unwind the attenuation products deepest-first, accumulate in sample order ------------
             size_t sample = 0;
@@ -327,6 +348,9 @@ int main(int argc, char **argv)
                     "host trace %.2f s, batched noise (incl. PCIe) %.3f s\n",
                     width, height, spp, opt.noise, opt.octave, total_points,
                     (double)total_points / ((double)width * height * spp), t_trace, t_noise);
+        if (opt.time_kernel)
+            std::printf("render: texture kernel alone on the renderer's hit-point stream: %.3f ms for %zu points = %.1f G points/s\n",
+                        t_kernel * 1e3, total_points, (double)total_points / t_kernel / 1e9);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "render: %s\n", e.what());
         return 1;
