@@ -179,6 +179,14 @@ WN_API int wn_eval3d_projected_points(const wn_tile *tile3d, const float *xyz_de
 WN_API int wn_multiband3d_points(const wn_tile *tile3d, const float *xyz_dev, size_t n, float s,
                                  int first_band, int nbands, const float *w_host,
                                  float var_per_band, float *out_dev, void *stream);
+/* The normal != NULL branch of the same Appendix-2 function: every band is WProjectedNoise =
+ * evaluate3DProjected (WaveletNoise.cpp:218-265); the paper divides by sqrt(sum w^2 * 0.296), the constant the
+ * reference uses for its projected grids (experient/main.cpp:72) -- pass it as var_per_band.  `normals_dev`
+ * holds one normal per point, or ONE normal for all points when one_normal != 0.  Absent from the reference. */
+WN_API int wn_multiband3d_projected_points(const wn_tile *tile3d, const float *xyz_dev,
+                                           const float *normals_dev, int one_normal, size_t n, float s,
+                                           int first_band, int nbands, const float *w_host,
+                                           float var_per_band, float *out_dev, void *stream);
 WN_API int wn_perlin_points(const wn_perm *perm, const double *xyz_dev, size_t n,
                             double *out_dev, void *stream); /* noise(x,y,z), perlin.h:42 */
 /* noise(const point3&) / turb / fractal_noise on float vec3 points (perlin.h:70-90). */

@@ -62,6 +62,7 @@ def lib():
     sig("wno_perlin_fractal", d, _i32p, f, f, f)
     sig("wno_perlin_turb", d, _i32p, f, f, f, i)
     sig("wno_multiband3d", f, vp, sz, _f32p, f, i, i, _f32p, f)
+    sig("wno_multiband3d_projected", f, vp, sz, _f32p, _f32p, f, i, i, _f32p, f)
     sig("wno_noise_texture_value", f, _i32p, d, i, _f32p)
     sig("wno_wavelet_texture_value", f, vp, sz, i, d, i, _f32p)
     sig("wno_grid_wavelet2d", None, _f32p, sz, i, i, _f32p)
@@ -202,6 +203,15 @@ def multiband3d(coef, pts, s, first_band, nbands, w, var):
     L = lib()
     return np.array([L.wno_multiband3d(_cptr(coef), coef.size, p, s, first_band, nbands, w, var)
                      for p in pts], np.float32)
+
+
+def multiband3d_projected(coef, pts, normals, s, first_band, nbands, w, var):
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3)
+    normals = np.ascontiguousarray(np.broadcast_to(np.asarray(normals, np.float32).reshape(-1, 3), pts.shape))
+    w = np.ascontiguousarray(w, np.float32)
+    L = lib()
+    return np.array([L.wno_multiband3d_projected(_cptr(coef), coef.size, p, n, s, first_band, nbands, w, var)
+                     for p, n in zip(pts, normals)], np.float32)
 
 
 def noise_texture_value(perm, scale, octave, pts):

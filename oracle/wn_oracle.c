@@ -367,6 +367,25 @@ float wno_multiband3d(const float *coef, size_t count, const float p[3], float s
     return result;
 }
 
+/* Cook & DeRose Appendix 2, the normal != NULL branch: every band is WProjectedNoise =
+ * evaluate3DProjected (WaveletNoise.cpp:218-265); the paper normalises with 0.296, the constant the
+ * reference also uses for its projected grids (experient/main.cpp:72).  Absent from the reference:
+ * pinned only as this composition of the pinned evaluate3DProjected. */
+float wno_multiband3d_projected(const float *coef, size_t count, const float p[3], const float normal[3],
+                                float s, int first_band, int nbands, const float *w, float var_per_band)
+{
+    float result = 0.0f, variance = 0.0f;
+    for (int b = 0; b < nbands && s + (float)first_band + (float)b < 0.0f; ++b) {
+        float q[3];
+        const float band_scale = (float)ldexp(1.0, first_band + b);
+        for (int a = 0; a < 3; ++a) q[a] = 2.0f * p[a] * band_scale;
+        result += w[b] * wno_evaluate3d_projected(coef, count, q, normal);
+    }
+    for (int b = 0; b < nbands; ++b) variance += w[b] * w[b];
+    if (variance != 0.0f) result /= sqrtf(variance * var_per_band);
+    return result;
+}
+
 /* ============================================================================================
  * Perlin (all fp64, perlin.h:18-31, 42-62)
  * ========================================================================================== */

@@ -84,6 +84,9 @@ double wno_perlin_turb(const int p[512], float x, float y, float z, int depth);
  * empirical 3-D value is 0.18402 (texture.h:84). */
 float wno_multiband3d(const float *coef, size_t count, const float p[3], float s,
                       int first_band, int nbands, const float *w, float var_per_band);
+/* the normal != NULL branch of the same Appendix-2 function (bands are evaluate3DProjected) */
+float wno_multiband3d_projected(const float *coef, size_t count, const float p[3], const float normal[3],
+                                float s, int first_band, int nbands, const float *w, float var_per_band);
 
 /* ---- texture adaptor (texture.h) ------------------------------------------------------------- */
 

@@ -495,3 +495,23 @@ def test_reference_named_generators_are_byte_identical_by_default(wn, noise3):
     for octave in (3, 4, 5):
         got = host(wn.generate3DSlicedOctaveBandNoise(256, octave, None, noise3)).ravel()
         assert (bits(got) == bits(raw(f"wavelet_noise_3Dsliced_octave_{octave}.raw"))).all(), octave
+
+
+def test_multiband_with_a_normal_points(wn, ora, noise3, tile3d_128):
+    """WMultibandNoise(p, s, normal, ...) (paper App. 2, normal != NULL): bands are evaluate3DProjected; bit-exact
+    against the oracle composition, with one normal for all points and with one normal per point."""
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-3, 3, (400, 3)).astype(np.float32)
+    w = [1.0, 0.5, 2.0]
+    one = np.array([[0.0, 0.0, 1.0]], np.float32)
+    got = host(noise3.WMultibandNoise(pts, -16.0, 0, 3, w, normal=one))
+    want = ora.multiband3d_projected(tile3d_128, pts, one, -16.0, 0, 3, w, 0.296)
+    assert (bits(got) == bits(want)).all()
+    nr = rng.normal(size=(400, 3)).astype(np.float32)
+    nr /= np.linalg.norm(nr, axis=1, keepdims=True).astype(np.float32)
+    got = host(noise3.WMultibandNoise(pts, -1.0, 0, 3, w, variance=0.25, normal=nr))
+    want = ora.multiband3d_projected(tile3d_128, pts, nr, -1.0, 0, 3, w, 0.25)
+    assert (bits(got) == bits(want)).all()
+    # scalar call shape
+    v = noise3.WMultibandNoise(pts[0], -16.0, 0, 3, w, normal=one)
+    assert np.float32(v) == ora.multiband3d_projected(tile3d_128, pts[:1], one, -16.0, 0, 3, w, 0.296)[0]

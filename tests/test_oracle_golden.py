@@ -170,6 +170,28 @@ def test_multiband_is_the_paper_composition(ora, gold, tile3d_128):
         assert (bits(got) == bits(acc)).all(), (s, first, nb)
 
 
+def test_multiband_with_a_normal_is_the_paper_composition(ora, gold, tile3d_128):
+    """The normal != NULL branch of Appendix 2: every band is evaluate3DProjected (pinned by the reference's
+    vectors elsewhere in this file), normalised with 0.296.  Parity unpinned by any reference artefact."""
+    pts = (gold["probe_pts"][-64:] * np.float32(0.5)).astype(np.float32)
+    w = np.array([1, 0.5, 2], np.float32)
+    for normal in ((0.0, 0.0, 1.0), (0.6, 0.0, 0.8)):
+        nr = np.broadcast_to(np.asarray(normal, np.float32), pts.shape).copy()
+        for s, first, nb in ((-16.0, 0, 3), (-1.0, 0, 3), (-16.0, -1, 2)):
+            acc = np.zeros(len(pts), np.float32)
+            for b in range(nb):
+                if not (np.float32(s) + np.float32(first) + np.float32(b) < 0):
+                    break
+                q = (np.float32(2) * pts * np.float32(2.0 ** (first + b))).astype(np.float32)
+                acc = (acc + w[b] * ora.evaluate3d_projected(tile3d_128, q, nr)).astype(np.float32)
+            var = np.float32(0)
+            for b in range(nb):
+                var = np.float32(var + w[b] * w[b])
+            acc = (acc / np.sqrt(np.float32(var * np.float32(0.296)))).astype(np.float32)
+            got = ora.multiband3d_projected(tile3d_128, pts, nr, s, first, nb, w, 0.296)
+            assert (bits(got) == bits(acc)).all(), (normal, s, first, nb)
+
+
 def test_textures(ora, gold, artefacts, tile2d_128, tile3d_128):
     tp = gold["tex_pts"]
     perm = ora.perlin_perm(5489)  # noise_texture holds a default-seeded perlin (texture.h:46)

@@ -77,6 +77,7 @@ SIGNATURES = {
     "wn_eval2d_points": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "wn_eval3d_projected_points": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "wn_multiband3d_points": (_i, [_vp, _vp, _sz, _f, _i, _i, C.POINTER(C.c_float), _f, _vp, _vp]),
+    "wn_multiband3d_projected_points": (_i, [_vp, _vp, _vp, _i, _sz, _f, _i, _i, C.POINTER(C.c_float), _f, _vp, _vp]),
     "wn_perlin_points": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "wn_perlin_points_vec3": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "wn_perlin_turb_points": (_i, [_vp, _vp, _sz, _i, _vp, _vp]),

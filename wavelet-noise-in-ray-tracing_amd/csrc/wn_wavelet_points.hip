@@ -29,6 +29,7 @@ struct PointsArgs {
     float band_scale[kMaxBands], band_w[kMaxBands];
     float out_div;
     int apply_div;
+    int one_normal; // multiband projected: `normals` holds ONE normal for all points
 };
 
 template <bool PADDED>
@@ -72,6 +73,25 @@ __global__ __launch_bounds__(256) void multiband3d_points_kernel(const PointsArg
             const float s = a.band_scale[b];
             v += a.band_w[b] * wn::eval3d_exact<PADDED>(a.coef, a.n, a.nmask, 2.0f * p[0] * s,
                                                 2.0f * p[1] * s, 2.0f * p[2] * s);
+        }
+        if (a.apply_div) v /= a.out_div;
+        a.out[i] = v;
+    }
+}
+
+// WMultibandNoise, normal != NULL branch: every band is evaluate3DProjected (WaveletNoise.cpp:218-265).
+__global__ __launch_bounds__(256) void multiband3d_projected_points_kernel(const PointsArgs a)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.count;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float *p = a.pts + 3 * i;
+        const float *nrp = a.normals + (a.one_normal ? 0 : 3 * i);
+        const float nr[3] = {nrp[0], nrp[1], nrp[2]};
+        float v = 0.0f;
+        for (int b = 0; b < a.nbands; ++b) {
+            const float s = a.band_scale[b];
+            const float q[3] = {2.0f * p[0] * s, 2.0f * p[1] * s, 2.0f * p[2] * s};
+            v += a.band_w[b] * wn::projected_exact(a.coef, a.n, a.nmask, q, nr);
         }
         if (a.apply_div) v /= a.out_div;
         a.out[i] = v;
@@ -282,6 +302,41 @@ int wn_multiband3d_points(const wn_tile *tile, const float *xyz_dev, size_t n, f
         hipLaunchKernelGGL(multiband3d_points_kernel<false>, dim3(point_blocks(n)), dim3(256), 0,
                            as_stream(stream), a);
     WN_LAUNCH_CHECK("multiband3d_points_kernel");
+    return WN_OK;
+}
+
+int wn_multiband3d_projected_points(const wn_tile *tile, const float *xyz_dev, const float *normals_dev,
+                                    int one_normal, size_t n, float s, int first_band, int nbands,
+                                    const float *w_host, float var_per_band, float *out_dev, void *stream)
+{
+    WN_ENTRY();
+    int rc = require_device();
+    if (rc) return rc;
+    if (nbands < 0 || nbands > kMaxBands)
+        return fail(WN_ERR_INVALID, "nbands must be in 0..%d (got %d)", kMaxBands, nbands);
+    if (nbands && !w_host) return fail(WN_ERR_INVALID, "w_host is NULL");
+    PointsArgs a{};
+    rc = fill_common(tile, 3, xyz_dev, n, out_dev, &a);
+    if (rc || n == 0) return rc;
+    if (!normals_dev) return fail(WN_ERR_INVALID, "normals_dev is NULL");
+    a.coef = tile->dev; // the projected evaluator indexes the linear layout
+    a.pts = xyz_dev;
+    a.normals = normals_dev;
+    a.one_normal = one_normal ? 1 : 0;
+    a.out = out_dev;
+    int active = 0;
+    while (active < nbands && s + (float)first_band + (float)active < 0.0f) ++active;
+    float variance = 0.0f;
+    for (int b = 0; b < nbands; ++b) variance += w_host[b] * w_host[b];
+    a.nbands = active;
+    for (int b = 0; b < active; ++b) {
+        a.band_scale[b] = ldexpf(1.0f, first_band + b);
+        a.band_w[b] = w_host[b];
+    }
+    a.apply_div = variance != 0.0f;
+    a.out_div = a.apply_div ? sqrtf(variance * var_per_band) : 1.0f;
+    hipLaunchKernelGGL(multiband3d_projected_points_kernel, dim3(point_blocks(n)), dim3(256), 0, as_stream(stream), a);
+    WN_LAUNCH_CHECK("multiband3d_projected_points_kernel");
     return WN_OK;
 }
 

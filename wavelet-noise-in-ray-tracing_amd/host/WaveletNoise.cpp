@@ -76,6 +76,21 @@ float WaveletNoise::WMultibandNoise(const float p[3], float sarg, int firstBand,
     return s.out_host()[0];
 }
 
+float WaveletNoise::WMultibandNoise(const float p[3], float sarg, const float *normal, int firstBand,
+                                    int nbands, const float *w, float variance) const
+{
+    if (!normal) return WMultibandNoise(p, sarg, firstBand, nbands, w, variance);
+    auto &s = wnhost::Scratch::get();
+    std::copy(p, p + 3, s.in_host());
+    std::copy(normal, normal + 3, s.in_host() + 4);
+    const float *in = static_cast<const float *>(s.in_dev());
+    check(wn_multiband3d_projected_points(tile(3), in, in + 4, 1, 1, sarg, firstBand, nbands, w, variance,
+                                          static_cast<float *>(s.out_dev()), nullptr),
+          "wn_multiband3d_projected_points");
+    check(wn_stream_sync(nullptr), "wn_stream_sync");
+    return s.out_host()[0];
+}
+
 // ---- batched members ----------------------------------------------------------------------------------
 void WaveletNoise::evaluate2D(const float *xy, size_t n, float *out) const
 {

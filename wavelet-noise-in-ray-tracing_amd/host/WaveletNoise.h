@@ -57,6 +57,10 @@ class WaveletNoise {
                           float variance = 0.18402f) const;
     void WMultibandNoise(const float *xyz, size_t n, float s, int firstBand, int nbands,
                          const float *w, float variance, float *out) const;
+    // The paper's full signature: normal != nullptr makes every band WProjectedNoise (evaluate3DProjected) and
+    // normalises with 0.296; normal == nullptr is the overload above with the paper's 0.210 replaced by `variance`.
+    float WMultibandNoise(const float p[3], float s, const float *normal, int firstBand, int nbands,
+                          const float *w, float variance = 0.296f) const;
     // The device-resident tile (an empty tile before generate*); for the C-ABI grid entry points.
     const wn_tile *tile(int dims) const;
 

@@ -192,12 +192,25 @@ class WaveletNoise:
             nr = nr.expand(pts.shape[0], 3).contiguous()
         return self._points(_lib.wn_eval3d_projected_points, 3, p, 3, extra=nr)
 
-    def WMultibandNoise(self, p, s, firstBand, nbands, w, variance=0.18402):
-        """Cook & DeRose Appendix 2 (normal == NULL branch); absent from the reference."""
+    def WMultibandNoise(self, p, s, firstBand, nbands, w, variance=None, normal=None):
+        """Cook & DeRose Appendix 2; absent from the reference.  normal=None: bands are WNoise = evaluate3D
+        (variance defaults to the reference's empirical 0.18402); with a normal (one for all points, or one per
+        point) bands are WProjectedNoise = evaluate3DProjected (variance defaults to 0.296)."""
         single = _is_scalar_point(p, 3)
         pts = _dev(p, torch.float32).reshape(-1, 3)
         out = torch.empty(pts.shape[0], dtype=torch.float32, device="cuda")
         wa = (C.c_float * max(1, nbands))(*[float(x) for x in list(w)[:nbands]])
+        if normal is not None:
+            nr = _dev(normal, torch.float32).reshape(-1, 3)
+            one = nr.shape[0] == 1
+            if not one and nr.shape[0] != pts.shape[0]:
+                raise ValueError("normal: one vector, or one per point")
+            check(_lib.wn_multiband3d_projected_points(self._handle(3), _ptr(pts), _ptr(nr), int(one), pts.shape[0],
+                                                       float(s), int(firstBand), int(nbands), wa,
+                                                       float(0.296 if variance is None else variance), _ptr(out),
+                                                       _stream()))
+            return float(out.item()) if single else out
+        variance = 0.18402 if variance is None else variance
         check(_lib.wn_multiband3d_points(self._handle(3), _ptr(pts), pts.shape[0], float(s),
                                          int(firstBand), int(nbands), wa, float(variance),
                                          _ptr(out), _stream()))
