@@ -515,3 +515,56 @@ def test_multiband_with_a_normal_points(wn, ora, noise3, tile3d_128):
     # scalar call shape
     v = noise3.WMultibandNoise(pts[0], -16.0, 0, 3, w, normal=one)
     assert np.float32(v) == ora.multiband3d_projected(tile3d_128, pts[:1], one, -16.0, 0, 3, w, 0.296)[0]
+
+
+def test_entry_points_from_several_host_threads_and_rand_is_preserved(wn, ora, noise3, tile3d_128):
+    """per-device facts sit in mutex-protected tables and the rand() park/restore is depth-counted,
+    so several host threads may be inside the library at once.  Four threads run different entry points (dense grid,
+    Perlin grid, point list, scalar mailbox calls) concurrently, each on its own stream; every result must equal the
+    single-threaded one, and the process's rand() stream must be the one it would be without the library."""
+    import ctypes
+    import threading
+    libc = ctypes.CDLL(None)
+    libc.srand(4242)
+    expected_rand = [libc.rand() for _ in range(8)]
+    libc.srand(4242)
+    first_half = [libc.rand() for _ in range(4)]
+
+    per = wn.perlin(12345)
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-20, 20, (5000, 3)).astype(np.float32)
+    want_vol = host(wn.wavelet_volume(noise3, 512, 512, 16, 0, 4, 4))
+    want_per = host(wn.perlin_volume(per, 256, 256, 16, 0, 4, 4))
+    want_pts = host(noise3.evaluate3D(pts))
+    want_scalar = [noise3.evaluate3D(pts[i]) for i in range(50)]
+    torch.cuda.synchronize()
+    errors = []
+
+    def run(kind):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for _ in range(6):
+                    if kind == 0:
+                        got = host(wn.wavelet_volume(noise3, 512, 512, 16, 0, 4, 4))
+                        assert (bits(got) == bits(want_vol)).all()
+                    elif kind == 1:
+                        got = host(wn.perlin_volume(per, 256, 256, 16, 0, 4, 4))
+                        assert (bits(got) == bits(want_per)).all()
+                    elif kind == 2:
+                        got = host(noise3.evaluate3D(pts))
+                        assert (bits(got) == bits(want_pts)).all()
+                    else:
+                        got = [noise3.evaluate3D(pts[i]) for i in range(50)]
+                        assert got == want_scalar
+        except Exception as e:  # noqa: BLE001
+            errors.append((kind, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    second_half = [libc.rand() for _ in range(4)]
+    assert first_half + second_half == expected_rand  # dozens of launches later the caller's stream is untouched
