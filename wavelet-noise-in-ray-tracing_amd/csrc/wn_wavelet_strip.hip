@@ -53,9 +53,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kCW = 4;          // compute waves per workgroup = rows per item
 constexpr int kSW = kCW;        // store waves per workgroup (one per compute wave)
 constexpr int kCols = 96;       // coefficient columns an item may touch (host: 255*step + 7 <= 96)
-constexpr int kPlanes = 37;     // coefficient planes an item may touch (host: (chunk_len-1)*step + 5 <= 37)
+#ifndef WN_STRIP_PLANES
+#define WN_STRIP_PLANES 37
+#define WN_STRIP_CHUNK 128
+#endif
+constexpr int kPlanes = WN_STRIP_PLANES;     // coefficient planes an item may touch (host: (chunk_len-1)*step + 5 <= 37)
 constexpr int kRowFloats = 96;  // table row = kCols
-constexpr int kMaxChunk = 128;  // planes per item (z table: 16 B per plane)
+constexpr int kMaxChunk = WN_STRIP_CHUNK;  // planes per item (z table: 16 B per plane)
 constexpr int kRRow = 100;      // one R row (96 columns + pad)
 constexpr int kTableFloats = kPlanes * kCW * kRowFloats; // the item's coefficient table [plane][tile row 0..3][96]
 constexpr int kStageFloats = 4 * kCW * 256; // two pairs of steps x one 1-KiB output row per compute wave and step
@@ -400,9 +404,13 @@ int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_
     if (step > 0.0) chunk_max = (int)std::min<double>(kMaxChunk, std::floor((kPlanes - 5 - slack) / step) + 1.0);
     if (chunk_max < 8) return WN_OK;
     // owner ranges: every workgroup slot of the chip (two per CU) should get one, as long as a range keeps >= 32 planes
-    const long long wgs = 2LL * cus;
+    long long wgs = 2LL * cus;
     int nranges = 1;
     while (groups * nranges < wgs && (g.nz + 2 * nranges - 1) / (2 * nranges) >= 32) nranges *= 2;
+#ifdef WN_TUNE_ENV
+    if (const char *e = getenv("WN_STRIP_WGS")) wgs = (long long)atoi(e) * cus;
+    if (const char *e = getenv("WN_STRIP_RANGES")) nranges = atoi(e);
+#endif
     StripArgs a{};
     a.coef = tile->dev;
     a.out = out_dev;
