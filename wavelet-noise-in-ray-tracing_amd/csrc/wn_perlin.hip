@@ -190,62 +190,79 @@ __global__ __launch_bounds__(64 * kRunWaves) void perlin_grid_run_kernel(const P
             // the run's 8 cell indices in one read
             const uint64_t cells = *reinterpret_cast<const uint64_t *>(xcell + (size_t)oc * kRunX + lane * kRun);
 
-            // Segments of the run that stay inside one cell (at the BASELINE lattice: the whole run).  Both loops
-            // are rolled and q is a per-lane value -- everything indexed by q lives in LDS -- so the corner state
-            // K / mm / tt is defined once per segment and never copied between branches (the unrolled form with a
-            // conditional re-hash per sample spent a third of its instructions on such copies).
-            int q = 0;
-            while (q < kRun) {
-                const int X = (int)((cells >> (8 * q)) & 255u);
-                // the segment's cell: hash its 8 corners (perlin.h:55-61) and fetch their {K, mm, t}
-                double K[8];
-                uint32_t mm[8], tt[8];
-                {
-                    const int A = perm[X] + Y, AA = perm[A] + Z, AB = perm[A + 1] + Z;
-                    const int B = perm[X + 1] + Y, BA = perm[B] + Z, BB = perm[B + 1] + Z;
-                    const int h[8] = {perm[AA], perm[BA], perm[AB], perm[BB],
-                                      perm[AA + 1], perm[BA + 1], perm[AB + 1], perm[BB + 1]};
+            // The corner state of the cell a lane is in: K, the and-mask and the sign-xor of its 8 corners.
+            double K[8];
+            uint32_t mm[8], tt[8];
+            // hash the cell's 8 corners (perlin.h:55-61) and fetch their {K, mm, t}.  (Keeping the hashes of a lane's
+            // previous row in a register -- a wave keeps its y row and walks z, so the cell is usually the same --
+            // measured no gain: 266-273 vs 255-265 us.)
+            auto hash_cell = [&](int X) {
+                const int A = perm[X] + Y, AA = perm[A] + Z, AB = perm[A + 1] + Z;
+                const int B = perm[X + 1] + Y, BA = perm[B] + Z, BB = perm[B + 1] + Z;
+                const int h[8] = {perm[AA], perm[BA], perm[AB], perm[BB],
+                                  perm[AA + 1], perm[BA + 1], perm[AB + 1], perm[BB + 1]};
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const RunKEntry e = ktab[(c >> 1) * 16 + (h[c] & 15)];
-                        K[c] = e.K;
-                        mm[c] = e.mm;
-                        tt[c] = e.t;
-                    }
+                for (int c = 0; c < 8; ++c) {
+                    const RunKEntry e = ktab[(c >> 1) * 16 + (h[c] & 15)];
+                    K[c] = e.K;
+                    mm[c] = e.mm;
+                    tt[c] = e.t;
                 }
-                auto sample = [&](int qs, const RunAxisEntry &x) {
-                    const double xf = x.f, u = x.fade, xm1 = xf - 1.0;
-                    const uint64_t b0 = (uint64_t)__double_as_longlong(xf), b1 = (uint64_t)__double_as_longlong(xm1);
-                    double gr[8];
+            };
+            auto sample = [&](int qs, const RunAxisEntry &x) {
+                const double xf = x.f, u = x.fade, xm1 = xf - 1.0;
+                const uint64_t b0 = (uint64_t)__double_as_longlong(xf), b1 = (uint64_t)__double_as_longlong(xm1);
+                double gr[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) gr[c] = wn::run_gradient(K[c], mm[c], tt[c], (c & 1) ? b1 : b0);
-                    const double x00 = wn::plerp(u, gr[0], gr[1]), x10 = wn::plerp(u, gr[2], gr[3]);
-                    const double x01 = wn::plerp(u, gr[4], gr[5]), x11 = wn::plerp(u, gr[6], gr[7]);
-                    const double nv = wn::plerp(w, wn::plerp(v, x00, x10), wn::plerp(v, x01, x11));
-                    double sum;
-                    if (KIND == kNoise) sum = nv;
-                    else {
-                        const double before = oc ? acc[qs * 64] : 0.0;
-                        sum = (KIND == kTurb) ? before + weight * nv : before + nv * weight;
-                    }
-                    if (oc + 1 < depth) acc[qs * 64] = sum;
-                    else { // last octave: finish the sample and park it in its own slot
-                        if (KIND == kTurb) sum = fabs(sum);
-                        if (KIND == kFractal) sum = sum / (amp_sum + weight);
-                        *reinterpret_cast<float *>(acc + qs * 64) = (float)sum * g.out_scale;
-                    }
-                };
+                for (int c = 0; c < 8; ++c) gr[c] = wn::run_gradient(K[c], mm[c], tt[c], (c & 1) ? b1 : b0);
+                const double x00 = wn::plerp(u, gr[0], gr[1]), x10 = wn::plerp(u, gr[2], gr[3]);
+                const double x01 = wn::plerp(u, gr[4], gr[5]), x11 = wn::plerp(u, gr[6], gr[7]);
+                const double nv = wn::plerp(w, wn::plerp(v, x00, x10), wn::plerp(v, x01, x11));
+                double sum;
+                if (KIND == kNoise) sum = nv;
+                else {
+                    const double before = oc ? acc[qs * 64] : 0.0;
+                    sum = (KIND == kTurb) ? before + weight * nv : before + nv * weight;
+                }
+                if (oc + 1 < depth) acc[qs * 64] = sum;
+                else { // last octave: finish the sample and park it in its own slot
+                    if (KIND == kTurb) sum = fabs(sum);
+                    if (KIND == kFractal) sum = sum / (amp_sum + weight);
+                    *reinterpret_cast<float *>(acc + qs * 64) = (float)sum * g.out_scale;
+                }
+            };
+            const bool one_cell = cells == (cells & 255u) * 0x0101010101010101ull;
+            if (__all(one_cell)) {
+                // Every lane's run stays in one cell (the BASELINE lattice, and every octave of turb up to a step
+                // of 1/8): one hash, then the 8 samples straight-line with a wave-uniform q -- LDS offsets become
+                // immediates and there is no per-sample loop control.
+                hash_cell((int)(cells & 255u));
+#pragma unroll
+                for (int qs = 0; qs < kRun; ++qs) {
+                    sample(qs, xe[qs * 64]);
+                    if (qs & 1) __builtin_amdgcn_sched_barrier(0); // pairs of samples: all eight interleaved need > 128 VGPRs
+                }
+            } else {
+                // Segments of the run that stay inside one cell.  Both loops are rolled and q is a per-lane value --
+                // everything indexed by q lives in LDS -- so the corner state is defined once per segment and never
+                // copied between branches (an unrolled form with a conditional re-hash per sample spent a third of
+                // its instructions on such copies).
                 auto cell_at = [&](int qq) { return (int)((cells >> (8 * qq)) & 255u); };
-                RunAxisEntry x = xe[q * 64];
-                bool more;
-                do { // one sample per trip; two per trip (more ILP, half the loop control) measured the same
-                    const int q1 = min(q + 1, kRun - 1);
-                    const RunAxisEntry xnext = xe[q1 * 64]; // requested before this sample's arithmetic
-                    sample(q, x);
-                    ++q;
-                    more = q < kRun && cell_at(q1) == X;
-                    x = xnext;
-                } while (more);
+                int q = 0;
+                while (q < kRun) {
+                    const int X = cell_at(q);
+                    hash_cell(X);
+                    RunAxisEntry x = xe[q * 64];
+                    bool more;
+                    do { // one sample per trip; two per trip (more ILP, half the loop control) measured the same
+                        const int q1 = min(q + 1, kRun - 1);
+                        const RunAxisEntry xnext = xe[q1 * 64]; // requested before this sample's arithmetic
+                        sample(q, x);
+                        ++q;
+                        more = q < kRun && cell_at(q1) == X;
+                        x = xnext;
+                    } while (more);
+                }
             }
             if (KIND == kFractal) amp_sum += weight;
             weight *= 0.5;
