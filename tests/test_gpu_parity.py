@@ -568,3 +568,90 @@ def test_entry_points_from_several_host_threads_and_rand_is_preserved(wn, ora, n
     assert not errors, errors
     second_half = [libc.rand() for _ in range(4)]
     assert first_half + second_half == expected_rand  # dozens of launches later the caller's stream is untouched
+
+
+def test_perlin_run_kernel_odd_shapes_steps_and_descriptors(wn, ora):
+    """The cell-sharing Perlin kernel (rows of >= 128 samples) on shapes and lattices that are not the benchmark's:
+    rows that are no multiple of 8 / 512, bricks cut by ny / nz, steps from 1/128 to > 1 (several cells per run:
+    the per-lane segment loops), a negative range, a constant z, a non-power-of-two divisor, an unaligned output --
+    noise, turb and fractal_noise, every value bit for bit against the oracle's scalar noise()."""
+    import ctypes as C
+    from importlib import import_module
+    nm = import_module("wavelet-noise-in-ray-tracing_amd.noise")
+    p = wn.perlin(5489)
+    perm = ora.perlin_perm(5489)
+
+    def coords(n, den, base_range, oscale):
+        i = np.arange(n, dtype=np.float32)
+        return ((i / np.float32(den)) * np.float32(base_range)) * np.float32(oscale)
+
+    cases = [  # den, nx, ny, z0, z1, base_range, octave_scale, z_const or None
+        (512, 512, 9, 3, 12, 4.0, 16.0, None),      # bricks cut in y and z
+        (131, 131, 5, 0, 3, 4.0, 16.0, None),       # ragged row, non-power-of-two divisor
+        (300, 643, 3, 7, 9, 4.0, 1.0, None),        # two x segments, the second ragged; step 1/75
+        (256, 256, 4, 0, 2, 4.0, 77.0, None),       # step 1.2: a new cell every sample
+        (256, 200, 4, 1, 2, 4.0, 19.2, None),       # step 0.3: cells change inside runs at lane-dependent places
+        (256, 256, 3, 0, 2, -4.0, 8.0, None),       # negative coordinates, descending
+        (256, 256, 6, 0, 1, 4.0, 32.0, 0.37),       # constant z (the "sliced" generators)
+    ]
+    for den, nx, ny, z0, z1, base_range, oscale, zc in cases:
+        cx, cy = coords(nx, den, base_range, oscale), coords(ny, den, base_range, oscale)
+        cz = np.full(1, np.float32(zc), np.float32) if zc is not None else coords(z1, den, base_range, oscale)[z0:z1]
+        nz = len(cz)
+        pts = np.stack(np.broadcast_arrays(cx[None, None, :], cy[None, :, None], cz[:, None, None]), axis=-1).reshape(-1, 3)
+        g = wn.GridSpec(den, nx, ny, z0, z1, base_range=base_range, octave_scale=oscale,
+                        z_mode=nm.WN_Z_CONST if zc is not None else nm.WN_Z_LATTICE, z_const=zc or 0.0)
+        buf = torch.empty(nz * ny * nx + 1, dtype=torch.float32, device="cuda")
+        for shift in (0, 1):  # shift 1: the output rows are not 16-byte aligned (scalar stores)
+            out = buf[shift:shift + nz * ny * nx]
+            gc = g.c()
+            nm.check(nm._lib.wn_perlin_grid(p._h, C.byref(gc), nm._ptr(out), nm._stream()))
+            want = ora.perlin_noise(perm, pts.astype(np.float64)).astype(np.float32)
+            assert (bits(host(out)) == bits(want)).all(), ("noise", den, nx, ny, oscale, shift)
+        nm.check(nm._lib.wn_perlin_turb_grid(p._h, C.byref(gc), 5, nm._ptr(out), nm._stream()))
+        want = ora.perlin_turb(perm, pts, 5).astype(np.float32)
+        assert (bits(host(out)) == bits(want)).all(), ("turb", den, nx, ny, oscale)
+        nm.check(nm._lib.wn_perlin_fractal_grid(p._h, C.byref(gc), nm._ptr(out), nm._stream()))
+        want = ora.perlin_fractal(perm, pts).astype(np.float32)
+        assert (bits(host(out)) == bits(want)).all(), ("fractal", den, nx, ny, oscale)
+
+
+def test_scalar_entry_points_conventions_and_errors(wn, ora, noise3, noise2, tile3d_128):
+    """wn_scalar_*: the reference's value-level conventions (empty tile -> 0.0f, no-tile texture -> 0.5), argument
+    errors reported like every other entry point, restart after the resident kernel's idle exit, and agreement with
+    the batched kernels for every op."""
+    import ctypes as C
+    import time
+    from importlib import import_module
+    nm = import_module("wavelet-noise-in-ray-tracing_amd.noise")
+    lib = nm._lib
+    f3 = (C.c_float * 3)(1.25, -3.75, 100.1)
+    out = C.c_float(-1)
+    empty = wn.WaveletNoise(128, 1)
+    assert lib.wn_scalar_eval3d(empty._handle(3), f3, C.byref(out)) == 0 and out.value == 0.0
+    assert lib.wn_scalar_wavelet_texture(None, 1, 1.0, 4, f3, C.byref(out)) == 0 and out.value == 0.5
+    assert lib.wn_scalar_eval3d(None, f3, C.byref(out)) == nm._capi.WN_ERR_INVALID
+    assert lib.wn_scalar_eval3d(noise2._handle(2), f3, C.byref(out)) == nm._capi.WN_ERR_INVALID  # 2-D tile
+    assert b"3-D tile" in lib.wn_last_error()
+    # every op against its batched twin
+    rng = np.random.default_rng(9)
+    pts = rng.uniform(-30, 30, (64, 3)).astype(np.float32)
+    nrm = np.array([0.0, 0.6, 0.8], np.float32)
+    per = wn.perlin(12345)
+    wt, pt = wn.wavelet_texture(1.0, 4, True), wn.noise_texture(1.0, 4)
+    b3, b2 = host(noise3.evaluate3D(pts)), host(noise2.evaluate2D(pts[:, :2]))
+    bp = host(noise3.evaluate3DProjected(pts, nrm))
+    bn, bt, bf = host(per.noise(pts)), host(per.turb(pts, 4)), host(per.fractal_noise(pts))
+    bw, bq = host(wt.grey(pts)), host(pt.grey(pts))
+    for i in (0, 1, 2, 33, 63):
+        if i == 33:
+            time.sleep(0.02)  # the resident kernel has ended by now (2 ms idle): the next call restarts it
+        assert np.float32(noise3.evaluate3D(pts[i])) == b3[i]
+        assert np.float32(noise2.evaluate2D(pts[i, :2])) == b2[i]
+        assert np.float32(noise3.evaluate3DProjected(pts[i], nrm)) == bp[i]
+        assert per.noise(pts[i]) == bn[i] and per.turb(pts[i], 4) == bt[i] and per.fractal_noise(pts[i]) == bf[i]
+        assert per.noise(float(pts[i, 0]), float(pts[i, 1]), float(pts[i, 2])) == bn[i]
+        assert np.float32(wt.value(0, 0, pts[i])[0]) == bw[i] and np.float32(pt.value(0, 0, pts[i])[0]) == bq[i]
+    calls, launches = C.c_ulonglong(0), C.c_ulonglong(0)
+    assert lib.wn_scalar_stats(C.byref(calls), C.byref(launches)) == 0
+    assert calls.value >= 45 and 1 <= launches.value <= calls.value
