@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -63,6 +64,25 @@ struct SepArgs {
     int xw; // wave columns per brick (1 or 2)
     BandArgs band[kMaxBands];
 };
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{}).
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+// Bands of one multiband call are consecutive octaves: the band d below the top one has a step <= (1/3) / 2^d, so
+// its coefficient box has at most box_rows_bound(d) (k, j) rows and spans at most box_col_groups(d, brick_x) groups
+// of 64 columns (the host checks both).  A single band is d = 0.
+__host__ __device__ constexpr int box_rows_bound(int d) { return d == 0 ? 36 : (d == 1 ? 25 : 16); }
+__host__ __device__ constexpr int box_col_groups(int d, int brick_x)
+{
+    return ((brick_x / 3 >> (d > 4 ? 4 : d)) + 8 + 63) / 64;
+}
 
 // Bijective XCD-aware remap: hardware deals consecutive workgroup ids round-robin over the 8
 // XCDs, so ids congruent mod 8 share an L2.  Give each XCD one contiguous range of workgroups
@@ -174,43 +194,64 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
     };
 
     // Box rows are (k, j) pairs, r = k*ey + j; wave w takes rows w, w+kWaves, ...: the row part of every
-    // address is scalar, a lane contributes only its column (256-B coalesced reads); a box spans up
-    // to kColGroups groups of 64 columns, pf[t][c] holds row t of this wave, column group c.
+    // address is scalar, a lane contributes only its column (256-B coalesced reads).
+    // Round 2: the bookkeeping of this phase was 40-50 % of the multiband kernel's instructions (~35 scalar and
+    // vector instructions per load: per-row while loops, 64-bit address arithmetic, a branch per load).  Now lane r
+    // computes row r's source offset and LDS slot ONCE per box (all rows in one instruction stream), a wave picks its
+    // rows' values with v_readlane; loads are unconditional with clamped indices (a few redundant, never stored);
+    // and rows / column groups per band are compile-time bounds (the lower bands' boxes are small).
     constexpr int kRowsPerWave = (kBoxY * kBoxZ + kWaves - 1) / kWaves;
     constexpr int kColGroups = (kBrickX / 3 + 8 + 63) / 64; // 64-column groups a box can span (step <= 1/3)
+    struct RowMap { int src, at; }; // per lane r: float offset of box row r in the tile, its slot k*kBoxY + j
+    auto row_map = [&](const Box &o) -> RowMap {
+        const int r = min(lane, o.nrows - 1);
+        int k = 0;
+#pragma unroll
+        for (int m = 1; m < kBoxZ; ++m) k += (r >= m * o.ey) ? 1 : 0;
+        const int j = r - k * o.ey;
+        RowMap rm;
+        rm.src = (((o.kz0 + k) & a.nmask) * a.n + ((o.jy0 + j) & a.nmask)) * a.n;
+        rm.at = k * kBoxY + j;
+        return rm;
+    };
+    // D = the band's depth below the top band (compile time): rows per wave and column groups
+    auto issue_rows = [&](const Box &o, const RowMap &rm, float (*pfr)[kColGroups], auto dc) {
+        constexpr int D = decltype(dc)::value;
+        constexpr int RW = (box_rows_bound(D) + kWaves - 1) / kWaves, CG = box_col_groups(D, kBrickX);
+#pragma unroll
+        for (int t = 0; t < RW; ++t) {
+            const int r = min(wave + kWaves * t, o.nrows - 1); // past the end: the last row again (not stored)
+            const float *row = a.coef + __builtin_amdgcn_readlane(rm.src, r);
+#pragma unroll
+            for (int c = 0; c < CG; ++c) pfr[t][c] = row[(o.ix0 + min(64 * c + lane, o.ex - 1)) & a.nmask];
+        }
+    };
+    auto commit_rows = [&](const Box &o, const RowMap &rm, int b, int box_buf, const float (*pfr)[kColGroups], auto dc) {
+        constexpr int D = decltype(dc)::value;
+        constexpr int RW = (box_rows_bound(D) + kWaves - 1) / kWaves, CG = box_col_groups(D, kBrickX);
+        float *col = lds + a.band[b].box_off + box_buf * a.box_buf_stride + lane * kColStride;
+#pragma unroll
+        for (int t = 0; t < RW; ++t) {
+            const int r = wave + kWaves * t;
+            if (r < o.nrows) {
+                const int at = __builtin_amdgcn_readlane(rm.at, r);
+#pragma unroll
+                for (int c = 0; c < CG; ++c)
+                    if (64 * c + lane < o.ex) col[64 * c * kColStride + at] = pfr[t][c];
+            }
+        }
+    };
+    // single band (NB == 1): one box in flight across phase 1
     float pf[kRowsPerWave][kColGroups];
+    RowMap pf_map;
     auto issue_box = [&](int buf, int b) -> Box {
         const Box o = box_of(buf, b);
-        int k = 0, j = wave;
-#pragma unroll
-        for (int t = 0; t < kRowsPerWave; ++t) {
-            while (j >= o.ey) { j -= o.ey; ++k; }
-            const bool row_on = wave + kWaves * t < o.nrows;
-            const float *row = a.coef + (((o.kz0 + k) & a.nmask) * a.n + ((o.jy0 + j) & a.nmask)) * a.n;
-#pragma unroll
-            for (int c = 0; c < kColGroups; ++c) {
-                pf[t][c] = 0.0f;
-                if (row_on && 64 * c < o.ex && lane + 64 * c < o.ex)
-                    pf[t][c] = row[(o.ix0 + 64 * c + lane) & a.nmask];
-            }
-            j += kWaves;
-        }
+        pf_map = row_map(o);
+        issue_rows(o, pf_map, pf, std::integral_constant<int, 0>{});
         return o; // geometry stays in SGPRs for commit_box
     };
     auto commit_box = [&](const Box &o, int b, int box_buf) {
-        float *col = lds + a.band[b].box_off + box_buf * a.box_buf_stride + lane * kColStride;
-        int k = 0, j = wave;
-#pragma unroll
-        for (int t = 0; t < kRowsPerWave; ++t) {
-            while (j >= o.ey) { j -= o.ey; ++k; }
-            if (wave + kWaves * t < o.nrows) {
-                const int at = k * kBoxY + j;
-#pragma unroll
-                for (int c = 0; c < kColGroups; ++c)
-                    if (64 * c < o.ex && lane + 64 * c < o.ex) col[64 * c * kColStride + at] = pf[t][c];
-            }
-            j += kWaves;
-        }
+        commit_rows(o, pf_map, b, box_buf, pf, std::integral_constant<int, 0>{});
     };
 
     // this lane's 4 x samples: window start (as a column of R) and 16 window weights per band;
@@ -275,6 +316,9 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
                 const float *c = lds + a.band[b].box_off + box_buf * a.box_buf_stride + kz * kBoxY + jy +
                                  i_begin * kColStride;
                 float *R = lds + a.band[b].r_off + r_buf * a.r_buf_stride + lane * rs_[b] + i_begin;
+                // several columns per trip: their LDS reads are in flight together (at two waves per SIMD a column
+                // per trip waited out its own read latency)
+#pragma unroll 4
                 for (int i = i_begin; i < i_end; ++i, c += kColStride, ++R) {
                     float acc = w9[0][0] * c[0];
 #pragma unroll
@@ -401,11 +445,22 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
             __syncthreads();
             phaseC(par);
         } else {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const Box ob = issue_box(tb, b);
-                commit_box(ob, b, 0);
-            }
+            // several bands: all bands' loads in flight together (29 registers for 5 bands of a 512-wide brick), then
+            // all commits.  (Two copies of the boxes with brick t+1's loads in flight during phase 1 of brick t were
+            // tried twice -- with the old and with this lean box code: 285 and 245-253 us against 261 and 225.)
+            float pfb[NB][kRowsPerWave][kColGroups];
+            Box ob[NB];
+            RowMap mapb[NB];
+            static_for<NB>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                ob[b] = box_of(tb, b);
+                mapb[b] = row_map(ob[b]);
+                issue_rows(ob[b], mapb[b], pfb[b], std::integral_constant<int, NB - 1 - b>{});
+            });
+            static_for<NB>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                commit_rows(ob[b], mapb[b], b, 0, pfb[b], std::integral_constant<int, NB - 1 - b>{});
+            });
             __syncthreads(); // boxes complete; previous phase C done (R free)
             phase1(tb, 0, 0);
             if (item + 2 < item_end) fill_tables(tb2, n2x, n2y, n2z);
@@ -577,6 +632,11 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
         auto extent = [&](int samples) { return (int)floor((samples - 1) * step + slack) + 1 + 3; };
         exs[b] = extent(kBrickX) + 1;
         if (extent(kBrickY) > kBoxY || (!g.z_const_mode && extent(BZ) > kBoxZ)) return false;
+        {   // the kernel's compile-time bounds per band (bands of one call are consecutive octaves)
+            const int d = nbands - 1 - b;
+            const int ez = g.z_const_mode ? 3 : extent(BZ);
+            if (extent(kBrickY) * ez > box_rows_bound(d) || exs[b] > 64 * box_col_groups(d, kBrickX)) return false;
+        }
         a->band[b].oscale = oscale[b];
         a->band[b].factor = (float)((double)(weights ? weights[b] : 1.0f) * (double)g.out_scale / (double)out_div);
         a->band[b].ex_cap = exs[b];
