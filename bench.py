@@ -298,7 +298,7 @@ def main():
             # 0.18 <= planes per lattice step <= 1/3 go to the strip-march kernel, other lattices to the brick kernel
             lattice_step = 4.0 * 2.0 ** OCTAVE * 2.0 / n
             strip = n % 256 == 0 and 0.18 <= lattice_step < 1.0 / 3.0
-            kernel = "grid3d_direct_kernel" if exact else ("grid3d_strip_kernel" if strip else "grid3d_sep_kernel<1")
+            kernel = "grid3d_exact_lds_kernel" if exact else ("grid3d_strip_kernel" if strip else "grid3d_sep_kernel<1")
             which = "configs[1]" if (world == 1 and n == 512 and planes == 512) else ("configs[4]" if sharded_volume and n == 2048 else "configs[4] shard shape" if (n, planes) == (2048, 256) else "custom lattice")
             desc = f"{slab_desc} dense 3D WNoise grid, tile={TILE}, octave={OCTAVE} ({which})"
     elif wl in ("turb7", "perlin"):

@@ -96,6 +96,9 @@ int check_handle_device(int handle_device, const char *what);
 // wn_wavelet_strip.hip: launches the strip-march kernel when the lattice is in its regime.
 int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_t stream, bool *launched);
 
+// wn_wavelet_exact.hip: bit-exact dense 3-D grids with the coefficient box staged in LDS; *launched tells the caller.
+int exact_lds_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_t stream, bool *launched);
+
 // wn_tilegen.hip: the filter half of generateNoiseTile2D/3D on the device.
 int tilegen_filter(wn_tile *t, const float *field_dev, hipStream_t stream);
 // wn_tilegen.hip: (re)build t->dev_padded from t->dev (no-op for 2-D tiles).

@@ -771,6 +771,15 @@ int wn_eval3d_grid(const wn_tile *tile, const wn_grid *grid, float *out_dev, voi
             if (rc || launched) return rc;
         }
     }
+    {   // bit-exact: the reference's 27-tap loop on an LDS-staged coefficient box when the bricks' boxes fit ...
+        bool launched = false;
+#ifdef WN_TUNE_ENV
+        if (!getenv("WN_NO_EXACT_LDS"))
+#endif
+        rc = exact_lds_try(tile, g, out_dev, as_stream(stream), &launched);
+        if (rc || launched) return rc;
+    }
+    // ... else on gathers from the tile
     DirectArgs d{};
     d.coef = tile->dev;
     d.out = out_dev;
