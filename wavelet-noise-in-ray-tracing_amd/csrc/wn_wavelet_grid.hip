@@ -604,6 +604,13 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
 {
     // two wave columns (512-sample bricks: whole 2-KiB rows written together) when the lattice is wide
     int xw = g.nx > 256 ? 2 : 1;
+    // 512-wide bricks write whole 2-KiB rows (~6 % faster than 256-wide ones at 1024^3), unless their last column
+    // would be mostly idle lanes (768 = 512 + 256: a quarter of all lanes): then 256-wide bricks, two workgroups per CU
+    // (768^3: 376 vs 434 us, profiles/r02_sep_knob_sweep.txt)
+    if (xw == 2) {
+        const double padded2 = (double)((g.nx + 511) / 512) * 512, padded1 = (double)((g.nx + 255) / 256) * 256;
+        if (padded2 > 1.1 * padded1) xw = 1;
+    }
 #ifdef WN_TUNE_ENV
     if (const char *e = getenv("WN_SEP_XW")) xw = atoi(e);
 #endif
@@ -670,7 +677,7 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
     return true;
 }
 
-// Persistent grid.  Single band: ONE workgroup per CU -- measured on MI355X (profiles/r02_sep_knob_sweep.txt):
+// Persistent grid.  Single band: ONE 8-wave workgroup per CU (two of the 4-wave workgroups of 256-wide bricks) -- measured on MI355X (profiles/r02_sep_knob_sweep.txt):
 // 2048 x 2048 x 256 slab 748 us with 1 workgroup per CU against 777-787 with 2-3, 1024^3 803 against 853-866; the
 // double-buffered one-barrier pipeline already overlaps a brick's loads, collapse and stores inside one
 // workgroup, and a second resident workgroup only adds contention on the store path.  Several bands: k workgroups
@@ -684,7 +691,7 @@ int persistent_grid(long long items, size_t lds_bytes, int xw, int nbands)
 #ifdef WN_TUNE_ENV
     if (const char *e = getenv("WN_SEP_K")) return (int)std::min<long long>(items, (long long)cus * std::min(kmax, atoi(e)));
 #endif
-    if (nbands == 1) return (int)std::min<long long>(items, cus);
+    if (nbands == 1) return (int)std::min<long long>(items, (long long)cus * (xw == 1 ? 2 : 1)); // 8 waves per CU either way
     int best_k = kmax;
     double best_eff = -1.0;
     for (int k = kmax; k >= (kmax > 4 ? 4 : 1); --k) {
