@@ -69,7 +69,7 @@ WN_API int wn_device_info(char *name, size_t name_len, int *compute_units, size_
 WN_API int wn_dev_alloc(void **dptr, size_t bytes);
 WN_API int wn_dev_free(void *dptr);
 /* Host memory the device can address (pinned + mapped): `*dev_alias` is the same bytes seen from
- * kernels.  The host classes use it to run scalar value(p) calls as one launch + one sync. */
+ * kernels.  (Scalar value(p) calls go through wn_scalar_* below, which keep their own mailbox.) */
 WN_API int wn_host_alloc_mapped(void **host_ptr, void **dev_alias, size_t bytes);
 WN_API int wn_host_free_mapped(void *host_ptr);
 WN_API int wn_copy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);

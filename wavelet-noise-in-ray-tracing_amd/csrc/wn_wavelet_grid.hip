@@ -1,6 +1,7 @@
 // wn_wavelet_grid.hip -- dense-grid wavelet noise for gfx950 (K1/K3/K3p/K5 of SURVEY.md 8).
 //
-// Two kernels stand under wn_eval3d_grid / wn_multiband3d_grid:
+// These kernels stand under wn_eval3d_grid / wn_multiband3d_grid (tried in this order; wn_eval3d_grid first offers
+// the lattice to the strip-march kernel of wn_wavelet_strip.hip):
 //
 //  * grid3d_sep_kernel<NB, XW>  (default).  A dense lattice is axis-aligned, so the 27-tap sum of
 //    WaveletNoise::evaluate3D (WaveletNoise.cpp:202-213) factors per axis:
@@ -15,9 +16,10 @@
 //    in-kernel (Cook & DeRose WMultibandNoise) with one store.
 //    Bound: HBM write stream, 4 B/sample (+ the 8 MiB tile, read ~twice, L2/MALL resident).
 //
-//  * grid3d_direct_kernel (WN_GRID_EXACT, or lattices the brick scheme does not cover: step
-//    > 1/3 cell per sample, negative steps).  One sample per lane, the reference's loop order
-//    and unfused arithmetic: bit-identical to evaluate3D.
+//  * WN_GRID_EXACT, or lattices the brick scheme does not cover (step > 1/3 cell per sample, negative steps):
+//    grid3d_exact_lds_kernel (wn_wavelet_exact.hip: the reference's 27-tap loop on an LDS-staged box) when a
+//    brick's box fits LDS, else grid3d_direct_kernel: one sample per lane, gathers from the tile.  Both keep
+//    the reference's loop order and unfused arithmetic: bit-identical to evaluate3D.
 //
 // 2-D and projected grids use direct kernels (bit-identical to evaluate2D / evaluate3DProjected).
 #include "wn_internal.hpp"

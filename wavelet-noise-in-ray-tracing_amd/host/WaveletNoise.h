@@ -6,8 +6,9 @@
 //                            exactly as the reference draws it (libstdc++ stream), filter passes
 //                            on the GPU (wn_tile_generate_from_field); coefficients stay
 //                            resident in HBM and are mirrored for getNoiseCoefficients().
-//   evaluate2D/3D/3DProjected(p) : one launch + one sync per call (bit-identical to the
-//                            reference); the batched overloads below are the fast path.
+//   evaluate2D/3D/3DProjected(p) : one request to the resident scalar kernel per call (wn_scalar_*,
+//                            ~4 us, bit-identical to the reference); the batched overloads below are
+//                            the fast path.
 #ifndef WAVELET_NOISE_H
 #define WAVELET_NOISE_H
 

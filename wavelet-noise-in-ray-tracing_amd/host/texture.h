@@ -1,8 +1,8 @@
 // texture.h -- the reference's texture adaptor (texture.h:14-115) over the MI355X C ABI.
 //
 // Same class names, constructors and `value(u, v, p)` signature, so material.h / main.cpp of the
-// reference compile against this header unchanged.  value() is one launch + one sync per call
-// and returns the reference's colour bit for bit; values() is the batched form a renderer should
+// reference compile against this header unchanged.  value() is one request to the resident scalar
+// kernel per call (wn_scalar_*, ~4 us) and returns the reference's colour bit for bit; values() is the batched form a renderer should
 // use (hit points in, grey levels out, optional per-hit `active` bytes compacted with wavefront
 // ballots on the device).
 #ifndef TEXTURE_H

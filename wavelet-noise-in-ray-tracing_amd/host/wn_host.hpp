@@ -1,5 +1,5 @@
-// wn_host.hpp -- glue shared by the host classes: error translation and the per-thread scratch
-// that turns a scalar value(p) call into one kernel launch + one stream sync through the C ABI.
+// wn_host.hpp -- glue shared by the host classes: error translation, a per-thread pinned scratch
+// (batch-of-one calls for the few members without a wn_scalar_* entry point) and a device buffer.
 //
 // There is no CPU arithmetic in the host classes: every evaluation, scalar or batched, runs on
 // the GPU through libwnoise_hip.so (include/wnoise.h).  A failing ABI call (most commonly: no
@@ -19,8 +19,9 @@ inline void check(int rc, const char *what)
     if (rc != WN_OK) throw std::runtime_error(std::string(what) + ": " + wn_last_error());
 }
 
-// Pinned, device-mapped staging for scalar calls: the kernel reads the point from and writes
-// the result to host memory, so a scalar call is launch + sync, with no memcpy calls.
+// Pinned, device-mapped staging for batch-of-one calls (WMultibandNoise): the kernel reads the point from and
+// writes the result to host memory, so such a call is launch + sync, with no memcpy calls.  The reference's own
+// scalar members (evaluate*, noise, value) use the resident scalar kernel instead (wn_scalar_*, include/wnoise.h).
 class Scratch {
   public:
     static Scratch &get()
