@@ -39,3 +39,42 @@ def test_config5_slabs_partition_the_2048_lattice():
             assert (z0, z1) == wn.slab_bounds(2048, world, r)  # bench.py's slabs are the library's slabs
             seen += [z0, z1]
         assert seen[0] == 0 and seen[-1] == 2048
+
+
+def test_cpu_baseline_evaluators_compute_the_workloads_they_are_timed_beside():
+    """bench.py's cpu_baseline leg drives the compiled reference (compositions for WMultibandNoise / turb, which the
+    reference lacks).  On a small lattice every evaluator must equal the oracle's restatement of the same workload bit
+    for bit -- otherwise the number printed beside the GPU's would be for something else."""
+    import importlib.util
+    import numpy as np
+    import oracle
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = 32
+    tile = oracle.tile3d(bench.TILE, bench.SEED)
+    perm = oracle.perlin_perm(bench.SEED)
+    want = {
+        "wavelet3d": lambda z: oracle.grid_wavelet3d_volume(tile, n, n, n, z, z + 1, bench.OCTAVE).ravel(),
+        "multiband5": lambda z: oracle.grid_multiband3d_volume(tile, n, n, n, z, z + 1, -16.0, 0, 5, [1.0] * 5, 0.18402).ravel(),
+        "perlin": lambda z: oracle.grid_perlin_volume(perm, n, n, n, z, z + 1, bench.OCTAVE).ravel(),
+        "turb7": lambda z: oracle.grid_turb_volume(perm, n, n, n, z, z + 1, 7).ravel(),
+    }
+    for wl, ref in want.items():
+        kind, units, run = bench.cpu_evaluator(wl, n, None)
+        assert units == n and kind in ("reference", "port")
+        for z in (0, 5, n - 1):
+            got = np.asarray(run(z), np.float32)
+            assert (got.view(np.uint32) == ref(z).view(np.uint32)).all(), (wl, kind, z)
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(-10, 10, (1 << 18, 3)).astype(np.float32)
+    for wl in ("texture_points", "texture_points_perlin"):
+        kind, units, run = bench.cpu_evaluator(wl, n, pts)
+        assert units == 2
+        got = np.asarray(run(1), np.float32)[:2000]
+        chunk = pts[1 << 17:][:2000]
+        if wl == "texture_points":
+            ref = oracle.wavelet_texture_value(tile, True, 1.0, bench.OCTAVE, chunk)
+        else:
+            ref = oracle.noise_texture_value(oracle.perlin_perm(5489), 1.0, bench.OCTAVE, chunk)
+        assert (got.view(np.uint32) == ref.view(np.uint32)).all(), (wl, kind)
