@@ -38,7 +38,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxBands = 8;
 constexpr int kBrickY = 8;    // sample rows per brick along y
-constexpr int kMaxBZ = 8;     // ... and along z (power of two <= 8, fewer for thin slabs)
+constexpr int kMaxBZ = 16;    // ... and along z (power of two: 16 for fine single-band lattices, 8, fewer for thin slabs)
+constexpr int kSlotZ = 8, kSlotX = kSlotZ + kMaxBZ; // table slots: 0..7 y samples, 8..23 z samples, 24/25 first/last x sample
 constexpr int kBoxY = 6;      // coefficient box: at most 6 rows in y and in z (8 samples, step <= 1/3)
 constexpr int kBoxZ = 6;
 constexpr int kColStride = kBoxY * kBoxZ + 1; // LDS floats per box column (odd: conflict-free fills)
@@ -125,10 +126,10 @@ template <int NB, int XW>
 __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
 {
     extern __shared__ float lds[];
-    // per-band sample tables, triple buffered: slots 0..7 y samples, 8..15 z samples,
-    // 16/17 first/last x sample of the brick
+    // per-band sample tables, triple buffered: slots 0..7 y samples, kSlotZ.. z samples,
+    // kSlotX / kSlotX+1 first/last x sample of the brick
     __shared__ int s_mid[3][NB][32];
-    __shared__ float s_w[3][NB][16][3];
+    __shared__ float s_w[3][NB][kSlotX][3];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -150,14 +151,14 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
 
     auto fill_tables = [&](int buf, int tbx, int tby, int tbz) {
         const int b = tid >> 5, slot = tid & 31;
-        if (b < NB && slot < 18) {
+        if (b < NB && slot < kSlotX + 2) {
             int idx;
             bool is_const = false;
             if (slot < 8) idx = min(tby * kBrickY + slot, g.ny - 1);
-            else if (slot < 16) {
-                idx = g.z0 + min(tbz * BZ + min(slot - 8, BZ - 1), g.nz - 1);
+            else if (slot < kSlotX) {
+                idx = g.z0 + min(tbz * BZ + min(slot - kSlotZ, BZ - 1), g.nz - 1);
                 is_const = g.z_const_mode != 0;
-            } else idx = (slot == 16) ? tbx * kBrickX : min(tbx * kBrickX + kBrickX - 1, g.nx - 1);
+            } else idx = (slot == kSlotX) ? tbx * kBrickX : min(tbx * kBrickX + kBrickX - 1, g.nx - 1);
             // band scale by selects: a per-lane index into the kernel arguments would become a
             // vector-memory load, and its vmcnt(0) wait would queue behind this wave's stores
             float oscale = a.band[0].oscale;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
             float w0, w1, w2;
             wn::bspline(c, m, w0, w1, w2);
             s_mid[buf][b][slot] = m;
-            if (slot < 16) {
+            if (slot < kSlotX) {
                 s_w[buf][b][slot][0] = w0;
                 s_w[buf][b][slot][1] = w1;
                 s_w[buf][b][slot][2] = w2;
@@ -183,9 +184,9 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
     auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     auto box_of = [&](int buf, int b) {
         Box o;
-        const int mx0 = sgpr(s_mid[buf][b][16]), mx1 = sgpr(s_mid[buf][b][17]);
+        const int mx0 = sgpr(s_mid[buf][b][kSlotX]), mx1 = sgpr(s_mid[buf][b][kSlotX + 1]);
         const int my0 = sgpr(s_mid[buf][b][0]), my1 = sgpr(s_mid[buf][b][kBrickY - 1]);
-        const int mz0 = sgpr(s_mid[buf][b][8]), mz1 = sgpr(s_mid[buf][b][8 + BZ - 1]);
+        const int mz0 = sgpr(s_mid[buf][b][kSlotZ]), mz1 = sgpr(s_mid[buf][b][kSlotZ + BZ - 1]);
         o.ix0 = mx0 - 1;
         o.ex = min(mx1 - mx0 + 4, a.band[b].ex_cap); // +3 support, +1 pad column (zero-weight tap)
         o.jy0 = my0 - 1;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
                 c = c * g.post_scale;
                 wn::bspline(c, m[q], w[q][0], w[q][1], w[q][2]);
             }
-            wbase[b] = m[0] - s_mid[buf][b][16]; // (m0 - 1) - ix0
+            wbase[b] = m[0] - s_mid[buf][b][kSlotX]; // (m0 - 1) - ix0
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const bool up = m[q] != m[0]; // mid is m[0] or m[0]+1 (host guarantees step <= 1/3)
@@ -300,24 +301,24 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
     auto phase1 = [&](int tb, int box_buf, int r_buf) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-            rs_[b] = min(sgpr(s_mid[tb][b][17]) - sgpr(s_mid[tb][b][16]) + 4, a.band[b].ex_cap) | 1;
-        if (lane < rows) {
-            const int yi = lane & (kBrickY - 1), zi = lane >> 3;
+            rs_[b] = min(sgpr(s_mid[tb][b][kSlotX + 1]) - sgpr(s_mid[tb][b][kSlotX]) + 4, a.band[b].ex_cap) | 1;
+        for (int row = lane; row < rows; row += 64) { // 64 rows per pass (16-plane bricks: two passes)
+            const int yi = row & (kBrickY - 1), zi = row >> 3;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const int ex = min(sgpr(s_mid[tb][b][17]) - sgpr(s_mid[tb][b][16]) + 4, a.band[b].ex_cap);
-                const int kz = s_mid[tb][b][8 + zi] - s_mid[tb][b][8];  // row's first box row in z
-                const int jy = s_mid[tb][b][yi] - s_mid[tb][b][0];      // ... and in y
+                const int ex = min(sgpr(s_mid[tb][b][kSlotX + 1]) - sgpr(s_mid[tb][b][kSlotX]) + 4, a.band[b].ex_cap);
+                const int kz = s_mid[tb][b][kSlotZ + zi] - s_mid[tb][b][kSlotZ];  // row's first box row in z
+                const int jy = s_mid[tb][b][yi] - s_mid[tb][b][0];                // ... and in y
                 float w9[3][3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) w9[k][j] = s_w[tb][b][8 + zi][k] * s_w[tb][b][yi][j];
+                    for (int j = 0; j < 3; ++j) w9[k][j] = s_w[tb][b][kSlotZ + zi][k] * s_w[tb][b][yi][j];
                 const int chunk = (ex + kWaves - 1) / kWaves;
                 const int i_begin = wave * chunk, i_end = min(ex, i_begin + chunk);
                 const float *c = lds + a.band[b].box_off + box_buf * a.box_buf_stride + kz * kBoxY + jy +
                                  i_begin * kColStride;
-                float *R = lds + a.band[b].r_off + r_buf * a.r_buf_stride + lane * rs_[b] + i_begin;
+                float *R = lds + a.band[b].r_off + r_buf * a.r_buf_stride + row * rs_[b] + i_begin;
                 // several columns per trip: their LDS reads are in flight together (at two waves per SIMD a column
                 // per trip waited out its own read latency)
 #pragma unroll 4
@@ -374,9 +375,12 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
                 reinterpret_cast<v4f *>(zrow + 4 * (size_t)g.nx)[lane] = v4f{acc[0], acc[1], acc[2], acc[3]};
                 zrow += plane;
             };
-            if (a.bz_log2 == 3) { // the common case, straight-line: LDS reads of later rows are hoisted over earlier FMAs
+            if (a.bz_log2 == 3) { // the common cases, straight-line: LDS reads of later rows are hoisted over earlier FMAs
 #pragma unroll
                 for (int zi = 0; zi < 8; ++zi) two_rows();
+            } else if (a.bz_log2 == 4) {
+#pragma unroll
+                for (int zi = 0; zi < 16; ++zi) two_rows();
             } else {
                 for (int zi = 0; zi < BZ; ++zi) two_rows();
             }
@@ -601,8 +605,8 @@ inline int ceil_pow2(int v)
 }
 
 // Plan the separable kernel; returns false when the lattice is outside its regime.
-bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *oscale,
-              const float *weights, float out_div, SepArgs *a, size_t *lds_bytes)
+bool plan_sep_bz(const wn_tile *tile, const GridArgs &g, int nbands, const float *oscale,
+                 const float *weights, float out_div, SepArgs *a, size_t *lds_bytes, int bz_cap)
 {
     // two wave columns (512-sample bricks: whole 2-KiB rows written together) when the lattice is wide
     int xw = g.nx > 256 ? 2 : 1;
@@ -622,7 +626,7 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
     if (pow2_mask(tile->n) < 0) return false; // the brick kernel wraps with a mask: power-of-two tiles
     if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0) return false;
     if (!g.z_const_mode && g.z0 < 0) return false; // negative plane indices: the exact kernel (bounds below assume indices >= 0)
-    int BZ = g.nz >= kMaxBZ ? kMaxBZ : ceil_pow2(g.nz);
+    int BZ = g.nz >= bz_cap ? bz_cap : ceil_pow2(g.nz); // planes per brick
 #ifdef WN_TUNE_ENV
     if (const char *e = getenv("WN_SEP_BZ")) BZ = std::min(BZ, atoi(e));
 #endif
@@ -677,6 +681,25 @@ bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *o
     a->g = g;
     a->inv_den = ((g.den & (g.den - 1)) == 0) ? 1.0f / (float)g.den : 0.0f;
     return true;
+}
+
+// Planes per brick: 8 (fewer for thin slabs); 16 for a single band on 256-wide bricks whose 16 planes still fit the
+// 6-row box and LDS (half the box loads, tables and barriers per sample).  Measured (profiles/r02_sep_knob_sweep.txt):
+// 768^3 (256-wide bricks) 322 vs 378-384 us; with 512-wide bricks no gain (1024^3 800 vs 791-826, 2048 x 2048 x 256
+// 743 vs 722), so those keep 8.
+bool plan_sep(const wn_tile *tile, const GridArgs &g, int nbands, const float *oscale,
+              const float *weights, float out_div, SepArgs *a, size_t *lds_bytes)
+{
+    if (nbands == 1 && !g.z_const_mode && g.nz >= 16) {
+        SepArgs a16{};
+        size_t lds16 = 0;
+        if (plan_sep_bz(tile, g, nbands, oscale, weights, out_div, &a16, &lds16, 16) && a16.xw == 1) {
+            *a = a16;
+            *lds_bytes = lds16;
+            return true;
+        }
+    }
+    return plan_sep_bz(tile, g, nbands, oscale, weights, out_div, a, lds_bytes, 8);
 }
 
 // Persistent grid.  Single band: ONE 8-wave workgroup per CU (two of the 4-wave workgroups of 256-wide bricks) -- measured on MI355X (profiles/r02_sep_knob_sweep.txt):
