@@ -175,6 +175,8 @@ def test_volume_goldens(wn, gold, artefacts, noise3):
     (512, 512, 8, 4096, 4104, 4),   # z beyond one tile period (weak-scaling shards)
     (768, 768, 8, 0, 8, 4),         # non power-of-two divisor, step 1/6
     (1000, 1000, 8, 0, 8, 4),       # inexact float division in the lattice coordinate
+    (768, 768, 9, 3, 40, 4),        # 256-wide bricks, 16 planes deep (37 planes: two full bricks and a ragged one in z)
+    (1280, 640, 5, 0, 21, 4),       # step .1: 256-wide bricks with a half-empty last column, 16-plane bricks
 ])
 def test_brick_path_vs_oracle(wn, ora, noise3, tile3d_128, den, nx, ny, z0, z1, octave):
     want = ora.grid_wavelet3d_volume(tile3d_128, den, nx, ny, z0, z1, octave)
