@@ -314,6 +314,24 @@ def test_texture_active_mask_compaction(wn, gold, frac):
         assert (bits(masked[active == 1]) == bits(full[active == 1])).all()
 
 
+def test_texture_plane_sorted_chunks_match_stream_order(wn):
+    """Lists of >= 64 K points take chunks in z-plane order when the stream is incoherent (wn_wavelet_points.hip,
+    wavelet_texture_sorted_kernel) and in stream order when it is coherent; both must give the floats of the
+    unsorted kernel, which the goldens pin (here: the same points in pieces below the threshold)."""
+    rng = np.random.default_rng(77)
+    n = 4096 * 40 + 1234
+    tex = wn.wavelet_texture(1.0, 4, True)
+    scattered = np.stack([rng.uniform(-10, 10, n), np.full(n, -0.5), rng.uniform(-10, 10, n)], 1).astype(np.float32)
+    sphere = rng.normal(size=(n, 3))
+    sphere = (2.0 * sphere / np.linalg.norm(sphere, axis=1, keepdims=True) + [0, 2, 0]).astype(np.float32)
+    coherent = np.stack([np.linspace(-10, 10, n), np.full(n, -0.5), np.repeat(rng.uniform(-10, 10, n // 512 + 1), 512)[:n]], 1).astype(np.float32)
+    mixed = np.concatenate([coherent[: 4096 * 20], scattered[4096 * 20:]])  # the decision is per chunk
+    for pts in (scattered, sphere, coherent, mixed):
+        whole = host(tex.grey(pts))
+        pieces = np.concatenate([host(tex.grey(pts[i:i + 30000])) for i in range(0, n, 30000)])
+        assert (bits(whole) == bits(pieces)).all()
+
+
 # ---- size-independent properties at BASELINE sizes ---------------------------------------------------------------------
 def test_full_512_cubed_properties(wn, ora, noise3, tile3d_128):
     """Config 2 at full size: periodicity, slab consistency, statistics and spot checks."""
