@@ -331,7 +331,7 @@ def main():
         tex_pts = pts
         samples_per_rank = m
         alg_bytes = 16 * m  # 12 B xyz in + 4 B out
-        kernel = "noise_texture_kernel" if perlin_tex else "wavelet_texture_sorted_kernel"
+        kernel = "noise_texture_kernel" if perlin_tex else "plane_sorted_points_kernel"
         desc = f"{m} ray hit points, {'noise_texture (Perlin)' if perlin_tex else 'wavelet_texture'} octave {OCTAVE} (configs[3] stand-in)"
         dtype = "f64" if perlin_tex else "f32"
         if perlin_tex:

@@ -125,6 +125,29 @@ def test_large_random_point_list_vs_oracle(wn, noise3, ora, tile3d_128):
     assert (bits(got) == bits(want)).all()
 
 
+def test_long_point_lists_take_plane_ordered_chunks_bit_exact(wn, noise3, ora, tile3d_128):
+    """evaluate3D / WMultibandNoise lists of >= 64 K points go through plane_sorted_points_kernel (chunks of 4,096 points
+    in z-plane order, or in stream order when already coherent): same floats as the oracle and as the plain kernels
+    (the same points in pieces below the threshold)."""
+    rng = np.random.default_rng(11)
+    n = 4096 * 20 + 777
+    scattered = rng.uniform(-40, 40, (n, 3)).astype(np.float32)
+    planar = scattered.copy()
+    planar[:, 1] = -0.5
+    coherent = np.stack([np.linspace(-40, 40, n), np.full(n, 0.25), np.repeat(rng.uniform(-40, 40, n // 256 + 1), 256)[:n]], 1).astype(np.float32)
+    w = [1.0, 0.5, 2.0, 1.0, 1.0]
+    for pts in (scattered, planar, coherent):
+        whole = host(noise3.evaluate3D(pts))
+        pieces = np.concatenate([host(noise3.evaluate3D(pts[i:i + 30000])) for i in range(0, n, 30000)])
+        assert (bits(whole) == bits(pieces)).all()
+        assert (bits(whole[:3000]) == bits(ora.evaluate3d(tile3d_128, pts[:3000]))).all()
+        small = (pts * np.float32(0.1)).astype(np.float32)  # band scales up to 32: keep the coordinates moderate
+        whole = host(noise3.WMultibandNoise(small, -16.0, 0, 5, w))
+        pieces = np.concatenate([host(noise3.WMultibandNoise(small[i:i + 30000], -16.0, 0, 5, w)) for i in range(0, n, 30000)])
+        assert (bits(whole) == bits(pieces)).all()
+        assert (bits(whole[:2000]) == bits(ora.multiband3d(tile3d_128, small[:2000], -16.0, 0, 5, w, 0.18402))).all()
+
+
 # ---- dense grids: the committed raws ---------------------------------------------------------------------
 @pytest.mark.parametrize("octave", (3, 4, 5))
 def test_committed_raw_grids(wn, noise2, noise3, octave):
@@ -316,7 +339,7 @@ def test_texture_active_mask_compaction(wn, gold, frac):
 
 def test_texture_plane_sorted_chunks_match_stream_order(wn):
     """Lists of >= 64 K points take chunks in z-plane order when the stream is incoherent (wn_wavelet_points.hip,
-    wavelet_texture_sorted_kernel) and in stream order when it is coherent; both must give the floats of the
+    plane_sorted_points_kernel) and in stream order when it is coherent; both must give the floats of the
     unsorted kernel, which the goldens pin (here: the same points in pieces below the threshold)."""
     rng = np.random.default_rng(77)
     n = 4096 * 40 + 1234

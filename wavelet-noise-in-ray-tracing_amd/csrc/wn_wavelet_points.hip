@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void wavelet_texture_kernel(const TexArgs a)
     }
 }
 
-// wavelet_texture::value over a chunk of hit points taken in z-plane order.  Ray hits are far from uniformly random
+// Long point lists (wavelet_texture::value, evaluate3D, WMultibandNoise): chunks of points taken in z-plane order.  Ray hits are far from uniformly random
 // in 3-D: most lie on planar surfaces (the reference's ground quad: y = const), so points that share the coefficient
 // plane mz of their z tap also share its few (y, z) rows -- 512-byte rows that 64 random x positions cover whole.  In
 // stream order a wave's 64 points touch ~576 lines; taken in mz order they share most of them (the gathers are bound by
@@ -198,43 +198,39 @@ __global__ __launch_bounds__(256) void wavelet_texture_kernel(const TexArgs a)
 // in stream order; 2.05 ms sorted with the values stored straight to memory (scattered 4-byte stores: WRITE_SIZE 10x);
 // 1.27 ms with the values staged; 1.19 ms with the x bits in the key.  The renderer's real stream: 74 -> 83 G points/s
 // (always sorting cost it 16 %; 16 K-point chunks with a two-pass sort were slower on both).
-constexpr int kSortChunk = 4096, kSortPlanes = 128, kSortPerThread = kSortChunk / 256;
+constexpr int kSortChunk = 4096, kSortPlanes = 128, kSortXBits = 3, kSortPerThread = kSortChunk / 256;
+constexpr int kSortBins = kSortPlanes << kSortXBits;
+constexpr size_t kSortMinPoints = 16 * (size_t)kSortChunk; // shorter lists: the plain kernels
 
-// XBITS: the key is the plane, then the top XBITS bits of the x tap's column (mod 128)
-template <bool MASKED, bool PADDED, int XBITS>
-__global__ __launch_bounds__(256) void wavelet_texture_sorted_kernel(const TexArgs a)
+// The kernel is generic over what a point is (`Ops`): count; active(i); mid_z(i) / mid_x(i) = the coefficient index of the
+// z / x tap's middle (of the finest band, where there are several); eval(i); store(i, v).
+template <typename Ops>
+__global__ __launch_bounds__(256) void plane_sorted_points_kernel(const Ops ops)
 {
-    constexpr int kBins = kSortPlanes << XBITS, kPer = kBins >= 256 ? kBins / 256 : 1;
-    __shared__ unsigned hist[kBins];
+    constexpr int kPer = kSortBins / 256;
+    __shared__ unsigned hist[kSortBins];
     __shared__ unsigned s_changes, wave_total[4];
     __shared__ unsigned short order[kSortChunk];
     __shared__ float value[kSortChunk];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t begin = (size_t)blockIdx.x * kSortChunk;
-    const int count = (int)min((size_t)kSortChunk, a.count - begin);
-    for (int b = tid; b < kBins; b += 256) hist[b] = 0;
+    const int count = (int)min((size_t)kSortChunk, ops.count - begin);
+    for (int b = tid; b < kSortBins; b += 256) hist[b] = 0;
     if (tid == 0) s_changes = 0;
     __syncthreads();
-    // the coefficient index of a coordinate's middle tap (texture.h:71-80, WaveletNoise.cpp:194-196)
-    auto mid_of = [&](float c) -> int {
-        float p = (float)((double)c * a.scale);
-        p *= a.octave_mul;
-        return (int)ceilf(p - 0.5f);
-    };
-    // sample: do neighbours of the stream change plane?
+    // sample (the chunk's first 256 points): do neighbours of the stream change plane?  (A second test, "... and share
+    // rows", would spare lists scattered in all three dimensions the 5 % the sorting passes cost them -- 25.4 -> 24.1 G
+    // points/s -- but it also turns away curved surfaces, which gain: the stand-in's sphere hits, 1.19 -> 1.34 ms.)
     {
-        const int k = mid_of(a.pts[3 * (begin + min(tid, count - 1)) + 2]);
+        const int k = ops.mid_z(begin + min(tid, count - 1));
         const int prev = __shfl_up(k, 1, 64);
         const unsigned long long diff = __ballot(lane != 0 && prev != k);
         if (lane == 0) atomicAdd(&s_changes, (unsigned)__popcll(diff));
     }
     __syncthreads();
     if (s_changes < 128) { // coherent already: stream order, no sorting passes
-        for (int i = tid; i < count; i += 256) {
-            if (MASKED && a.active[begin + i] == 0) continue;
-            const float *p = a.pts + 3 * (begin + i);
-            a.grey[begin + i] = wavelet_texture_value<PADDED>(a, p[0], p[1], p[2]);
-        }
+        for (int i = tid; i < count; i += 256)
+            if (ops.active(begin + i)) ops.store(begin + i, ops.eval(begin + i));
         return;
     }
     // pass 1: bin and rank of every point (one LDS atomic each)
@@ -244,10 +240,8 @@ __global__ __launch_bounds__(256) void wavelet_texture_sorted_kernel(const TexAr
         const int i = tid + 256 * k;
         key[k] = 0xffff;
         rank[k] = 0;
-        if (i < count && (!MASKED || a.active[begin + i] != 0)) {
-            const float *p = a.pts + 3 * (begin + i);
-            int bin = mid_of(p[2]) & (kSortPlanes - 1);
-            if (XBITS > 0) bin = (bin << XBITS) | ((mid_of(p[0]) & 127) >> (7 - XBITS));
+        if (i < count && ops.active(begin + i)) {
+            const int bin = ((ops.mid_z(begin + i) & (kSortPlanes - 1)) << kSortXBits) | ((ops.mid_x(begin + i) & 127) >> (7 - kSortXBits));
             key[k] = (unsigned short)bin;
             rank[k] = (unsigned short)atomicAdd(&hist[bin], 1u);
         }
@@ -255,10 +249,9 @@ __global__ __launch_bounds__(256) void wavelet_texture_sorted_kernel(const TexAr
     __syncthreads();
     { // exclusive prefix sum of the bins: kPer bins per thread, wave scan, wave totals
         unsigned mine[kPer], sum = 0;
-        const bool has = tid * kPer < kBins;
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
-            mine[j] = has ? hist[tid * kPer + j] : 0u;
+            mine[j] = hist[tid * kPer + j];
             sum += mine[j];
         }
         unsigned inc = sum;
@@ -271,12 +264,10 @@ __global__ __launch_bounds__(256) void wavelet_texture_sorted_kernel(const TexAr
         __syncthreads();
         unsigned run = inc - sum;
         for (int w = 0; w < wave; ++w) run += wave_total[w];
-        if (has) {
 #pragma unroll
-            for (int j = 0; j < kPer; ++j) {
-                hist[tid * kPer + j] = run;
-                run += mine[j];
-            }
+        for (int j = 0; j < kPer; ++j) {
+            hist[tid * kPer + j] = run;
+            run += mine[j];
         }
     }
     __syncthreads();
@@ -289,25 +280,76 @@ __global__ __launch_bounds__(256) void wavelet_texture_sorted_kernel(const TexAr
     const int n_active = (int)(wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3]);
     for (int s2 = tid; s2 < n_active; s2 += 256) {
         const int i = order[s2];
-        const float *p = a.pts + 3 * (begin + i);
-        value[i] = wavelet_texture_value<PADDED>(a, p[0], p[1], p[2]);
+        value[i] = ops.eval(begin + i);
     }
     __syncthreads();
     for (int i = tid; i < count; i += 256)
-        if (!MASKED || a.active[begin + i] != 0) a.grey[begin + i] = value[i];
+        if (ops.active(begin + i)) ops.store(begin + i, value[i]);
 }
 
-template <int XBITS>
-void launch_sorted(const TexArgs &a, bool masked, bool padded, dim3 grid, hipStream_t stream)
-{
-    const dim3 block(256);
-    if (masked) {
-        if (padded) hipLaunchKernelGGL((wavelet_texture_sorted_kernel<true, true, XBITS>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((wavelet_texture_sorted_kernel<true, false, XBITS>), grid, block, 0, stream, a);
-    } else {
-        if (padded) hipLaunchKernelGGL((wavelet_texture_sorted_kernel<false, true, XBITS>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((wavelet_texture_sorted_kernel<false, false, XBITS>), grid, block, 0, stream, a);
+__device__ __forceinline__ int mid_of(float p) { return (int)ceilf(p - 0.5f); } // WaveletNoise.cpp:194-196
+
+// wavelet_texture::value (texture.h:67-107) on a 3-D tile
+template <bool MASKED, bool PADDED>
+struct TextureOps {
+    TexArgs a;
+    size_t count;
+    __device__ bool active(size_t i) const { return !MASKED || a.active[i] != 0; }
+    __device__ int mid(float c) const // texture.h:71-80
+    {
+        float p = (float)((double)c * a.scale);
+        p *= a.octave_mul;
+        return mid_of(p);
     }
+    __device__ int mid_z(size_t i) const { return mid(a.pts[3 * i + 2]); }
+    __device__ int mid_x(size_t i) const { return mid(a.pts[3 * i]); }
+    __device__ float eval(size_t i) const
+    {
+        const float *p = a.pts + 3 * i;
+        return wavelet_texture_value<PADDED>(a, p[0], p[1], p[2]);
+    }
+    __device__ void store(size_t i, float v) const { a.grey[i] = v; }
+};
+
+// WaveletNoise::evaluate3D per point; nbands > 0: WMultibandNoise (keyed by its finest band, the last one)
+template <bool PADDED, bool MULTIBAND>
+struct Eval3dOps {
+    PointsArgs a;
+    size_t count;
+    __device__ bool active(size_t) const { return true; }
+    __device__ float key_scale() const { return a.band_scale[a.nbands - 1]; }
+    __device__ int mid_z(size_t i) const { return MULTIBAND ? mid_of(2.0f * a.pts[3 * i + 2] * key_scale()) : mid_of(a.pts[3 * i + 2]); }
+    __device__ int mid_x(size_t i) const { return MULTIBAND ? mid_of(2.0f * a.pts[3 * i] * key_scale()) : mid_of(a.pts[3 * i]); }
+    __device__ float eval(size_t i) const
+    {
+        const float *p = a.pts + 3 * i;
+        if (!MULTIBAND) return wn::eval3d_exact<PADDED>(a.coef, a.n, a.nmask, p[0], p[1], p[2]);
+        float v = 0.0f;
+        for (int b = 0; b < a.nbands; ++b) {
+            const float s = a.band_scale[b];
+            v += a.band_w[b] * wn::eval3d_exact<PADDED>(a.coef, a.n, a.nmask, 2.0f * p[0] * s, 2.0f * p[1] * s, 2.0f * p[2] * s);
+        }
+        if (a.apply_div) v /= a.out_div;
+        return v;
+    }
+    __device__ void store(size_t i, float v) const { a.out[i] = v; }
+};
+
+template <typename Ops>
+int launch_sorted(const Ops &ops, hipStream_t stream)
+{
+    const size_t blocks = (ops.count + kSortChunk - 1) / kSortChunk;
+    if (blocks > 0x7fffffffull) return WN_ERR_INVALID;
+    hipLaunchKernelGGL((plane_sorted_points_kernel<Ops>), dim3((unsigned)blocks), dim3(256), 0, stream, ops);
+    return WN_OK;
+}
+
+inline bool sort_enabled()
+{
+#ifdef WN_TUNE_ENV
+    if (getenv("WN_NO_POINT_SORT")) return false;
+#endif
+    return true;
 }
 
 inline int pow2_mask(int n) { return (n > 0 && (n & (n - 1)) == 0) ? n - 1 : -1; }
@@ -353,6 +395,13 @@ int wn_eval3d_points(const wn_tile *tile, const float *xyz_dev, size_t n, float 
     if (rc || n == 0) return rc;
     a.pts = xyz_dev;
     a.out = out_dev;
+    if (n >= kSortMinPoints && a.n > 0 && sort_enabled()) { // long lists: chunks in z-plane order (plane_sorted_points_kernel)
+        const int lrc = tile->dev_padded ? launch_sorted(Eval3dOps<true, false>{a, n}, as_stream(stream))
+                                         : launch_sorted(Eval3dOps<false, false>{a, n}, as_stream(stream));
+        if (lrc) return fail(lrc, "too many points");
+        WN_LAUNCH_CHECK("plane_sorted_points_kernel(evaluate3D)");
+        return WN_OK;
+    }
     if (tile->dev_padded)
         hipLaunchKernelGGL(eval3d_points_kernel<true>, dim3(point_blocks(n)), dim3(256), 0, as_stream(stream), a);
     else
@@ -423,6 +472,13 @@ int wn_multiband3d_points(const wn_tile *tile, const float *xyz_dev, size_t n, f
     }
     a.apply_div = variance != 0.0f;
     a.out_div = a.apply_div ? sqrtf(variance * var_per_band) : 1.0f;
+    if (n >= kSortMinPoints && a.n > 0 && a.nbands >= 1 && sort_enabled()) { // long lists: chunks in the finest band's z-plane order
+        const int lrc = tile->dev_padded ? launch_sorted(Eval3dOps<true, true>{a, n}, as_stream(stream))
+                                         : launch_sorted(Eval3dOps<false, true>{a, n}, as_stream(stream));
+        if (lrc) return fail(lrc, "too many points");
+        WN_LAUNCH_CHECK("plane_sorted_points_kernel(WMultibandNoise)");
+        return WN_OK;
+    }
     if (tile->dev_padded)
         hipLaunchKernelGGL(multiband3d_points_kernel<true>, dim3(point_blocks(n)), dim3(256), 0,
                            as_stream(stream), a);
@@ -501,22 +557,17 @@ int wn_wavelet_texture_points(const wn_tile *tile, int use_3d, double scale, int
     const bool padded = has_tile && use_3d && tile->dev_padded;
     if (padded) a.coef = tile->dev_padded;
     const dim3 grid((unsigned)blocks), block(256);
-    // 3-D tile and enough points: chunks taken in z-plane order (see wavelet_texture_sorted_kernel)
-    bool sorted = a.mode == 3 && n >= 16 * (size_t)kSortChunk;
+    // 3-D tile and enough points: chunks taken in z-plane order (see plane_sorted_points_kernel)
+    bool sorted = a.mode == 3 && n >= kSortMinPoints;
 #ifdef WN_TUNE_ENV
-    if (getenv("WN_NO_TEX_SORT")) sorted = false;
+    if (getenv("WN_NO_POINT_SORT")) sorted = false;
 #endif
     if (sorted) {
-        const size_t sblocks = (n + kSortChunk - 1) / kSortChunk;
-        if (sblocks > 0x7fffffffull) return fail(WN_ERR_INVALID, "too many points");
-        const dim3 sgrid((unsigned)sblocks);
-        int xbits = 3;
-#ifdef WN_TUNE_ENV
-        if (const char *e = getenv("WN_TEX_XBITS")) xbits = atoi(e);
-#endif
-        if (xbits == 0) launch_sorted<0>(a, active_dev != nullptr, padded, sgrid, as_stream(stream));
-        else launch_sorted<3>(a, active_dev != nullptr, padded, sgrid, as_stream(stream));
-        WN_LAUNCH_CHECK("wavelet_texture_sorted_kernel");
+        int lrc;
+        if (active_dev) lrc = padded ? launch_sorted(TextureOps<true, true>{a, n}, as_stream(stream)) : launch_sorted(TextureOps<true, false>{a, n}, as_stream(stream));
+        else lrc = padded ? launch_sorted(TextureOps<false, true>{a, n}, as_stream(stream)) : launch_sorted(TextureOps<false, false>{a, n}, as_stream(stream));
+        if (lrc) return fail(lrc, "too many points");
+        WN_LAUNCH_CHECK("plane_sorted_points_kernel(texture)");
         return WN_OK;
     }
     if (active_dev) {
