@@ -355,6 +355,39 @@ def test_texture_plane_sorted_chunks_match_stream_order(wn):
         assert (bits(whole) == bits(pieces)).all()
 
 
+def test_dispatcher_fuzz_default_kernels_vs_exact(wn, noise3):
+    """Random lattices through wn_eval3d_grid / wn_multiband3d_grid: whatever kernel the dispatcher picks (strip march,
+    brick, 16-plane brick, direct gathers) must stay within 1e-5 of WN_GRID_EXACT, which is bit-identical to the
+    reference (pinned by the tests above).  Shapes include rows that are / are not multiples of 256, odd sizes,
+    non-power-of-two denominators, steps on both sides of every regime edge, and offsets into the lattice."""
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for case in range(40):
+        nx = int(rng.choice([64, 100, 192, 256, 257, 320, 512, 768, 1024]))
+        ny = int(rng.choice([1, 3, 8, 13, 32, 70]))
+        nz = int(rng.choice([1, 2, 5, 16, 33, 140]))
+        while nx * ny * nz > 6_000_000:
+            nz = max(1, nz // 2)
+        den = int(rng.choice([128, 200, 256, 384, 512, 640, 1024, 2048]))
+        octave = int(rng.integers(0, 6))
+        z0 = int(rng.choice([0, 1, 7, 100, 511]))
+        fast = wn.wavelet_volume(noise3, den, nx, ny, z0, z0 + nz, octave)
+        exact = wn.wavelet_volume(noise3, den, nx, ny, z0, z0 + nz, octave, exact=True)
+        err = float((fast - exact).abs().max())
+        assert err <= TOL, ("wavelet_volume", den, nx, ny, z0, nz, octave, err)
+        worst = max(worst, err)
+        if case % 2 == 0:
+            nb = int(rng.integers(1, 6))
+            first = int(rng.integers(-2, 3))
+            w = [float(x) for x in rng.uniform(0.25, 2.0, nb)]
+            fast = wn.multiband_volume(noise3, den, nx, ny, z0, z0 + nz, -16.0, first, nb, w)
+            exact = wn.multiband_volume(noise3, den, nx, ny, z0, z0 + nz, -16.0, first, nb, w, exact=True)
+            err = float((fast - exact).abs().max())
+            assert err <= TOL, ("multiband_volume", den, nx, ny, z0, nz, first, nb, err)
+            worst = max(worst, err)
+    assert worst > 0.0  # the separable kernels did run (their sums are ordered differently)
+
+
 # ---- size-independent properties at BASELINE sizes ---------------------------------------------------------------------
 def test_full_512_cubed_properties(wn, ora, noise3, tile3d_128):
     """Config 2 at full size: periodicity, slab consistency, statistics and spot checks."""
