@@ -429,6 +429,27 @@ def main():
                                          "bytes": nbytes, "how": "torch zero_ / copy_ of the output buffer, HIP events, same run"}
             if bound == "hbm":
                 roofline["frac_of_measured_fill"] = roofline["achieved"] / roofline["measured_peak"]["fill_GBps"]
+            if wl == "wavelet3d" and world == 1:
+                # beside the contract's single-stream figure: the same launches alternating between two streams and two
+                # output buffers, so that the ramp and tail of consecutive launches overlap (informational, never `value`)
+                second = torch.empty_like(out)
+                lanes = [(torch.cuda.Stream(), out), (torch.cuda.Stream(), second)]
+
+                def piped(k):
+                    for i in range(k):
+                        st, buf = lanes[i & 1]
+                        with torch.cuda.stream(st):
+                            wn.wavelet_volume(noise, n, n, n, z0, z1, OCTAVE, out=buf)
+
+                piped(4)
+                torch.cuda.synchronize()
+                p0 = time.perf_counter()
+                piped(args.steps)
+                torch.cuda.synchronize()
+                pdt = time.perf_counter() - p0
+                roofline["two_stream_pipeline"] = {"ms_per_step": pdt * 1e3 / args.steps, "Msamples_per_s": samples_per_rank * args.steps / pdt / 1e6,
+                                                   "how": "same launches alternating between 2 HIP streams / 2 output buffers; wall clock"}
+                del second, lanes
             for _ in range(2):
                 step()  # the buffer holds the workload's output again for the CPU comparison below
             torch.cuda.synchronize()
