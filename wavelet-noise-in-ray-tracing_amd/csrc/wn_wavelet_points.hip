@@ -197,7 +197,10 @@ __global__ __launch_bounds__(256) void wavelet_texture_kernel(const TexArgs a)
 // most neighbours of the stream lie in different planes.  Measured (80 M uniformly random quad / sphere hits): 2.65 ms
 // in stream order; 2.05 ms sorted with the values stored straight to memory (scattered 4-byte stores: WRITE_SIZE 10x);
 // 1.27 ms with the values staged; 1.19 ms with the x bits in the key.  The renderer's real stream: 74 -> 83 G points/s
-// (always sorting cost it 16 %; 16 K-point chunks with a two-pass sort were slower on both).
+// (always sorting cost it 16 %; 16 K-point chunks with a two-pass sort were slower on both).  Finer x keys (4 / 5 bits, 8 / 16 KB
+// of histogram) sort the stand-in 5 / 6.5 % faster but their LDS costs the stream-order chunks a workgroup per CU: the
+// renderer's stream 83 -> 81 / 74 G points/s.  (With histogram and values sharing their LDS all three run alike: the sorted
+// path likes four workgroups per CU -- their rows fit the L1 together -- the stream-order path more.)
 constexpr int kSortChunk = 4096, kSortPlanes = 128, kSortXBits = 3, kSortPerThread = kSortChunk / 256;
 constexpr int kSortBins = kSortPlanes << kSortXBits;
 constexpr size_t kSortMinPoints = 16 * (size_t)kSortChunk; // shorter lists: the plain kernels
