@@ -388,6 +388,31 @@ def test_dispatcher_fuzz_default_kernels_vs_exact(wn, noise3):
     assert worst > 0.0  # the separable kernels did run (their sums are ordered differently)
 
 
+def test_entry_points_capture_into_a_hip_graph(wn, noise3):
+    """The batched entry points only enqueue (no allocation, synchronisation or host read in the call), so a caller can
+    capture them into a hipGraph and replay it: dense grid, turb grid and a texture list in one graph."""
+    N = 256
+    p = wn.perlin(12345)
+    tex = wn.wavelet_texture(1.0, 4, True)
+    pts = torch.rand(100000, 3, device="cuda") * 8 - 4
+    want = (wn.wavelet_volume(noise3, N, N, N, 0, 16, 4).clone(), wn.turb_volume(p, N, N, N, 0, 8, 7).clone(), tex.grey(pts).clone())
+    outs = (torch.empty(N * N * 16, dtype=torch.float32, device="cuda"), torch.empty(N * N * 8, dtype=torch.float32, device="cuda"),
+            torch.empty(100000, dtype=torch.float32, device="cuda"))
+    torch.cuda.synchronize()
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            wn.wavelet_volume(noise3, N, N, N, 0, 16, 4, out=outs[0])
+            wn.turb_volume(p, N, N, N, 0, 8, 7, out=outs[1])
+            tex.grey(pts, out=outs[2])
+    for _ in range(2):
+        for o in outs:
+            o.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0].view(16, N, N), want[0]) and torch.equal(outs[1].view(8, N, N), want[1]) and torch.equal(outs[2], want[2])
+
+
 # ---- size-independent properties at BASELINE sizes ---------------------------------------------------------------------
 def test_full_512_cubed_properties(wn, ora, noise3, tile3d_128):
     """Config 2 at full size: periodicity, slab consistency, statistics and spot checks."""
