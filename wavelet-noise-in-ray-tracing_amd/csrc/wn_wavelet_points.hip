@@ -183,8 +183,8 @@ __global__ __launch_bounds__(256) void wavelet_texture_kernel(const TexArgs a)
     }
 }
 
-// Long point lists (wavelet_texture::value, evaluate3D, WMultibandNoise): chunks of points taken in z-plane order.  Ray hits are far from uniformly random
-// in 3-D: most lie on planar surfaces (the reference's ground quad: y = const), so points that share the coefficient
+// Long point lists (wavelet_texture::value, evaluate3D, WMultibandNoise): chunks of points taken in z-plane order.
+// Ray hits are far from uniformly random in 3-D: most lie on planar surfaces (the reference's ground quad: y = const), so points that share the coefficient
 // plane mz of their z tap also share its few (y, z) rows -- 512-byte rows that 64 random x positions cover whole.  In
 // stream order a wave's 64 points touch ~576 lines; taken in mz order they share most of them (the gathers are bound by
 // L1 misses: profiles/r02_point_kernel_tile_size_probe.txt).  A workgroup counting-sorts the indices of its chunk by mz
