@@ -30,8 +30,9 @@ def test_slab_bounds_partition_every_plane_once():
     assert wn.slab_bounds(2048, 8, 3) == (768, 1024)  # config 5: 256 planes per GPU
 
 
-@pytest.mark.parametrize("world,nz,dst", [(2, 8, 0), (3, 7, 0), (2, 5, 1), (4, 3, 0)])
-def test_gather_volume_gloo(world, nz, dst):
+@pytest.mark.parametrize("world,nz,dst,piece_bytes", [(2, 8, 0, 1 << 30), (3, 7, 0, 1 << 30), (2, 5, 1, 1 << 30), (4, 3, 0, 1 << 30),
+                                                      (2, 9, 0, 2 * 6 * 10 * 4), (3, 11, 2, 6 * 10 * 4)])
+def test_gather_volume_gloo(world, nz, dst, piece_bytes):
     port = free_port()
     procs = []
     for r in range(world):
@@ -39,7 +40,7 @@ def test_gather_volume_gloo(world, nz, dst):
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ROOT, "tests", "_shard_worker.py"),
-             str(nz), "6", "10", "16", "4", str(dst)], env=env, stdout=subprocess.PIPE,
+             str(nz), "6", "10", "16", "4", str(dst), str(piece_bytes)], env=env, stdout=subprocess.PIPE,
             stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):

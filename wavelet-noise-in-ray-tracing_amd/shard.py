@@ -18,7 +18,7 @@ def slab_bounds(nz, world_size, rank):
     return z0, z0 + base + (1 if rank < rem else 0)
 
 
-def gather_volume(slab, nz, dst=0, group=None, out=None):
+def gather_volume(slab, nz, dst=0, group=None, out=None, piece_bytes=1 << 30):
     """Collect z-slabs (each `slab` is [z1-z0, ny, nx], planes per slab_bounds) on rank `dst`.
 
     Returns the full [nz, ny, nx] volume on `dst`, None elsewhere.  Without an initialised
@@ -32,6 +32,9 @@ def gather_volume(slab, nz, dst=0, group=None, out=None):
         return slab
     ny, nx = slab.shape[-2], slab.shape[-1]
     slab = slab.contiguous()
+    # one grouped exchange; a slab travels in pieces of whole planes of at most `piece_bytes` (1 GiB) (a 2048^3 / 2 slab is 16 GiB:
+    # no single message near the 32-bit byte counts some transports still carry)
+    step = max(1, int(piece_bytes) // max(1, ny * nx * slab.element_size()))
     ops = []
     full = None
     if rank == dst:
@@ -44,11 +47,13 @@ def gather_volume(slab, nz, dst=0, group=None, out=None):
                 full[z0:z1].copy_(slab)
             else:
                 src = dist.get_global_rank(group, r) if group is not None else r
-                ops.append(dist.P2POp(dist.irecv, full[z0:z1], src, group))
+                for z in range(z0, z1, step):
+                    ops.append(dist.P2POp(dist.irecv, full[z:min(z + step, z1)], src, group))
     else:
         if slab.numel():
             peer = dist.get_global_rank(group, dst) if group is not None else dst
-            ops.append(dist.P2POp(dist.isend, slab, peer, group))
+            for z in range(0, slab.shape[0], step):
+                ops.append(dist.P2POp(dist.isend, slab[z:z + step], peer, group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
