@@ -87,17 +87,6 @@ __host__ __device__ constexpr int box_col_groups(int d, int brick_x)
     return ((brick_x / 3 >> (d > 4 ? 4 : d)) + 8 + 63) / 64;
 }
 
-// Bijective XCD-aware remap: hardware deals consecutive workgroup ids round-robin over the 8
-// XCDs, so ids congruent mod 8 share an L2.  Give each XCD one contiguous range of workgroups
-// (hence of bricks => a contiguous part of the volume and of the tile per L2).  Speed only.
-__device__ __forceinline__ int xcd_remap(int id, int total)
-{
-    const int q = total >> 3, r = total & 7;
-    const int xcd = id & 7, k = id >> 3;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + k;
-}
-
 // lattice_coord with the division replaced by an exact multiply when den is a power of two.
 __device__ __forceinline__ float lattice_coord_fast(int i, float den, float inv_den, float range,
                                                     float oscale, float post)
@@ -141,7 +130,11 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
     const int nyz = a.nby * a.nbz;
 
     const long long total_items = (long long)a.nbx * nyz;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    // Workgroups take their bricks in dispatch order.  (Hardware deals consecutive ids round-robin over the 8 XCDs; round 1 gave
+    // each XCD one contiguous eighth of the volume instead -- one L2 per part of the tile.  Measured in round 2: no gain, between
+    // 2 % slower and 1 % faster over six lattices on two boxes.  The tile reads it saves come out of the Infinity Cache beside the
+    // store stream and cost no time, as in the strip kernel: profiles/r02_strip_xcd_renumbering.txt.)
+    const int wg = (int)blockIdx.x;
     int item = (int)(total_items * wg / gridDim.x);
     const int item_end = (int)(total_items * (wg + 1) / gridDim.x);
     if (item >= item_end) return;
