@@ -30,9 +30,9 @@
 //   * The store wave paired with the compute wave moves each parked row to memory.  The barrier of
 //     step z sits in the middle of step z+1 and shares a statement with that step's R write, with a
 //     counted lgkmcnt: no LDS latency is waited out at the barrier.
-//   * The two workgroups of a CU swap wave priority every 64 planes (s_setprio): the arbiter
-//     otherwise favours the older workgroup all the way, which then finishes 15-20 us early and
-//     leaves the CU half empty (worth 5-8 % at 512^3).
+//   * The two workgroups of a CU take turns at the higher wave priority, 64 planes at a time, the younger one two
+//     turns of three (s_setprio): the arbiter otherwise favours the older workgroup all the way, which then finishes
+//     15-20 us early and leaves the CU half empty (worth 5-8 % at 512^3).
 // Per-axis mids / weights are computed exactly as the reference does (WaveletNoise.cpp:194-200);
 // only the order of the final sums differs (tolerance 1e-5, like the brick kernel).
 #include "wn_internal.hpp"
@@ -105,9 +105,15 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // The first half of the grid (dispatched first, one workgroup per CU) and the second half share the CUs; they
 // take turns at the higher wave priority, kPrioPeriod planes at a time.
 constexpr int kPrioPeriod = 64;
+// The later-dispatched workgroup of the pair has the turn twice out of three times: time stamps of pairs (round 2) showed the
+// turns are not symmetric -- with the older workgroup at the higher priority the younger one starves (9 us per 16 planes
+// against 4), with the younger one higher the older merely slows (4.2 against 3.2) -- so with equal turns the older still
+// finished 4-12 us early.  2 : 1 measured 1-7 % faster than 1 : 1 on four boxes (3 : 1 the same, "always" worse again).
 __device__ __forceinline__ void set_turn_priority(int turn)
 {
-    if (((blockIdx.x >= gridDim.x / 2) ^ (turn & 1)) != 0) __builtin_amdgcn_s_setprio(1);
+    const bool younger = blockIdx.x >= gridDim.x / 2;
+    const bool third = turn % 3 == 2;
+    if (younger != third) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
 }
 
