@@ -64,6 +64,7 @@ struct SepArgs {
     int nbands;
     float inv_den; // 1/den when den is a power of two (exact), else 0
     int vec4_ok;
+    int even_share_q10;
     int xw; // wave columns per brick (1 or 2)
     BandArgs band[kMaxBands];
 };
@@ -135,8 +136,13 @@ __global__ __launch_bounds__(256 * XW) void grid3d_sep_kernel(const SepArgs a)
     // 2 % slower and 1 % faster over six lattices on two boxes.  The tile reads it saves come out of the Infinity Cache beside the
     // store stream and cost no time, as in the strip kernel: profiles/r02_strip_xcd_renumbering.txt.)
     const int wg = (int)blockIdx.x;
-    int item = (int)(total_items * wg / gridDim.x);
-    const int item_end = (int)(total_items * (wg + 1) / gridDim.x);
+    // Workgroups 2k, 2k+1 (an even and an odd XCD) share their bricks unevenly: even_share_q10 / 1024 goes to the even one.
+    // In a store-bound launch every odd workgroup ends ~10 % later than its even neighbour with equal shares
+    // (profiles/r02_strip_pair_timestamps.txt); 53 : 47 for single-band lattices measured 1.3-2.2 % faster on two boxes
+    // (1024^3 812 -> 794 us, 2048 x 2048 x 256 721 -> 711, 768^3 386 -> 381); five bands (not store-bound) keep halves.
+    auto first_item = [&](int w) { return (int)((total_items * ((long long)(w & ~1) * 512 + ((w & 1) ? a.even_share_q10 : 0))) / ((long long)gridDim.x * 512)); };
+    int item = (gridDim.x & 1) ? (int)(total_items * wg / gridDim.x) : first_item(wg);
+    const int item_end = (gridDim.x & 1) ? (int)(total_items * (wg + 1) / gridDim.x) : (wg + 1 == (int)gridDim.x ? (int)total_items : first_item(wg + 1));
     if (item >= item_end) return;
     int bx = item / nyz;
     int bz = (item - bx * nyz) / a.nby;
@@ -792,6 +798,10 @@ int wn_eval3d_grid(const wn_tile *tile, const wn_grid *grid, float *out_dev, voi
         if (plan_sep(tile, g, 1, &os, nullptr, 1.0f, &a, &lds)) {
             a.out = out_dev;
             a.vec4_ok = (g.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
+            a.even_share_q10 = a.nbands == 1 ? 545 : 512;
+#ifdef WN_TUNE_ENV
+            if (const char *e = getenv("WN_SEP_EVEN_SHARE")) a.even_share_q10 = atoi(e);
+#endif
             rc = run_sep(a, lds, as_stream(stream), &launched);
             if (rc || launched) return rc;
         }
@@ -868,6 +878,10 @@ int wn_multiband3d_grid(const wn_tile *tile, const wn_grid *grid, float s, int f
         if (plan_sep(tile, gb, active, oscale, wts, out_div, &a, &lds)) {
             a.out = out_dev;
             a.vec4_ok = (g.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
+            a.even_share_q10 = a.nbands == 1 ? 545 : 512;
+#ifdef WN_TUNE_ENV
+            if (const char *e = getenv("WN_SEP_EVEN_SHARE")) a.even_share_q10 = atoi(e);
+#endif
             bool launched = false;
             rc = run_sep(a, lds, as_stream(stream), &launched);
             if (rc || launched) return rc;
