@@ -57,6 +57,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget (1 thread)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the gather of the slabs on rank 0")
     ap.add_argument("--no-measured-peak", action="store_true", help="skip the in-run fill / copy ceiling")
+    ap.add_argument("--two-stream-probe", action="store_true",
+                    help="also time the same launches alternating between two streams / two buffers (informational; off by "
+                         "default so that a rocprofv3 trace of this command holds only the contract's launches)")
     ap.add_argument("--print-launch", action="store_true",
                     help="print the command --gpus N would start and exit (no GPU is touched)")
     return ap.parse_args(argv)
@@ -429,7 +432,7 @@ def main():
                                          "bytes": nbytes, "how": "torch zero_ / copy_ of the output buffer, HIP events, same run"}
             if bound == "hbm":
                 roofline["frac_of_measured_fill"] = roofline["achieved"] / roofline["measured_peak"]["fill_GBps"]
-            if wl == "wavelet3d" and world == 1:
+            if wl == "wavelet3d" and world == 1 and args.two_stream_probe:
                 # beside the contract's single-stream figure: the same launches alternating between two streams and two
                 # output buffers, so that the ramp and tail of consecutive launches overlap (informational, never `value`)
                 second = torch.empty_like(out)

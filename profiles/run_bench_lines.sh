@@ -4,7 +4,7 @@
 TAG=${1:-r02}
 OUT=gpurun_out/bench_$TAG
 mkdir -p $OUT
-python bench.py --steps 50 --warmup 5 > $OUT/wavelet3d.json 2> $OUT/wavelet3d.err || echo "wavelet3d failed"
+python bench.py --steps 50 --warmup 5 --two-stream-probe > $OUT/wavelet3d.json 2> $OUT/wavelet3d.err || echo "wavelet3d failed"
 for wl in multiband5 turb7 perlin texture_points texture_points_perlin wavelet3d_exact; do
   python bench.py --workload $wl --steps 10 --warmup 2 --cpu-seconds 8 > $OUT/$wl.json 2> $OUT/$wl.err || echo "$wl failed"
 done
