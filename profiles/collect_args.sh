@@ -17,10 +17,10 @@ PASSES=(
   "WRITE_SIZE"
   "FETCH_SIZE"
 )
-run "$D/trace.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -- python3 $ROOT/bench.py "$@" --steps 10 --warmup 2 --no-cpu-baseline --no-measured-peak
+run "$D/trace.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -- python3 $ROOT/bench.py "$@" --steps 10 --warmup 2 --no-cpu-baseline --no-per-config --no-sustained --no-measured-peak
 i=0
 for pass in "${PASSES[@]}"; do
-  run "$D/pmc_$i.log" rocprofv3 --pmc $pass --output-format csv -d "$D/pmc_$i" -- python3 $ROOT/bench.py "$@" --steps 4 --warmup 1 --no-cpu-baseline --no-measured-peak
+  run "$D/pmc_$i.log" rocprofv3 --pmc $pass --output-format csv -d "$D/pmc_$i" -- python3 $ROOT/bench.py "$@" --steps 4 --warmup 1 --no-cpu-baseline --no-per-config --no-sustained --no-measured-peak
   i=$((i+1))
 done
 echo "collected $NAME"

@@ -34,11 +34,11 @@ PASSES=(
 for wl in $WORKLOADS; do
   D=$OUT/$wl
   mkdir -p "$D"
-  BENCH="python3 $ROOT/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline"
+  BENCH="python3 $ROOT/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-per-config --no-sustained"
   run "$D/trace.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -- $BENCH
   i=0
   for pass in "${PASSES[@]}"; do
-    run "$D/pmc_$i.log" rocprofv3 --pmc $pass --output-format csv -d "$D/pmc_$i" -- python3 $ROOT/bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline
+    run "$D/pmc_$i.log" rocprofv3 --pmc $pass --output-format csv -d "$D/pmc_$i" -- python3 $ROOT/bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline --no-per-config --no-sustained
     i=$((i+1))
   done
   echo "collected $wl"

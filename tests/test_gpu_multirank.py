@@ -73,6 +73,10 @@ def test_bench_launches_its_own_ranks_two_gloo_ranks_on_one_gpu():
     assert line["gather"]["peer_plane_matches_local_recompute"] is True
     assert line["gather"]["bytes_into_root"] == 4.0 * 512 * 512 * 256
     assert line["value"] > 0
+    # the N > 1 line carries its own single-GPU baseline of the SAME lattice (here 512^3: the north star's scaling lattice)
+    ss = line["strong_scaling"]
+    assert ss["lattice"] == [512, 512, 512] and ss["n"] == 2 and ss["n1_ms"] > 0 and ss["nN_ms"] > 0
+    assert 0 < ss["efficiency"] < 1.5  # two ranks sharing ONE GPU: ~0.5; the key exists and is sane
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL gather needs two GPUs")

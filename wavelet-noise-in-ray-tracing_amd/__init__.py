@@ -21,7 +21,7 @@ from .noise import (  # noqa: E402
     WaveletNoise, perlin, PerlinNoise, noise_texture, wavelet_texture, GridSpec,
     generate2DOctaveBandNoise, generate3DSlicedOctaveBandNoise,
     generate3DProjectedOctaveBandNoise, generatePerlinNoise2D, generatePerlinNoise3DSliced,
-    wavelet_volume, multiband_volume, perlin_volume, turb_volume, device_info, HipTimer,
+    wavelet_volume, wavelet_volume_launcher, multiband_volume, perlin_volume, turb_volume, device_info, HipTimer,
 )
 from .shard import slab_bounds, gather_volume  # noqa: E402
 from . import formats  # noqa: E402
@@ -31,6 +31,6 @@ __all__ = [
     "WaveletNoise", "perlin", "PerlinNoise", "noise_texture", "wavelet_texture", "GridSpec",
     "generate2DOctaveBandNoise", "generate3DSlicedOctaveBandNoise",
     "generate3DProjectedOctaveBandNoise", "generatePerlinNoise2D", "generatePerlinNoise3DSliced",
-    "wavelet_volume", "multiband_volume", "perlin_volume", "turb_volume", "device_info",
+    "wavelet_volume", "wavelet_volume_launcher", "multiband_volume", "perlin_volume", "turb_volume", "device_info",
     "HipTimer", "slab_bounds", "gather_volume", "formats",
 ]

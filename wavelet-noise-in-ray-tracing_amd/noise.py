@@ -472,6 +472,24 @@ def wavelet_volume(noise, den, nx, ny, z0, z1, octave, exact=False, out=None):
     return out[: g.nz * ny * nx].view(g.nz, ny, nx)
 
 
+def wavelet_volume_launcher(noise, den, nx, ny, z0, z1, octave, out, exact=False):
+    """The same call as wavelet_volume with its arguments marshalled once: returns launch(), one kernel launch into
+    `out` on the stream that is current NOW (for long back-to-back runs, where a few tens of microseconds of
+    argument handling per call would sit beside a 100 us kernel)."""
+    g = GridSpec(den, nx, ny, z0, z1, octave_scale=_octave_scale(octave), post_scale=2.0,
+                 out_scale=_inv_stddev(0.18402), flags=WN_GRID_EXACT if exact else WN_GRID_DEFAULT)
+    out = g.empty(out)
+    gc, h, p, st, fn = g.c(), noise._handle(3), _ptr(out), _stream(), _lib.wn_eval3d_grid
+    ref = C.byref(gc)
+
+    def launch():
+        rc = fn(h, ref, p, st)
+        if rc:
+            check(rc)
+    launch.keep = (gc, noise, out)
+    return launch
+
+
 def multiband_volume(noise, den, nx, ny, z0, z1, s=-16.0, firstBand=0, nbands=5, w=None,
                      variance=0.18402, exact=False, out=None):
     """Config 3(A): WMultibandNoise(p=(i/den)*4, s, NULL, firstBand, nbands, w)."""
