@@ -780,3 +780,60 @@ def test_full_512_cubed_perlin_and_turb_planes_and_properties(wn, ora):
         want = ora.grid_turb_volume(perm, 512, 512, 512, z, z + 1, 7)[0]
         assert (bits(host(tv[z])) == bits(want)).all(), z
     assert float(tv.min()) >= 0.0 and bool(torch.isfinite(tv).all())
+
+
+# ---- WMultibandNoise on dense lattices: the plane-pipeline kernel (wn_wavelet_multiband.hip) ------------------------------
+def test_multiband_plane_pipeline_shapes_vs_exact_kernel_and_oracle(wn, ora, noise3, tile3d_128):
+    """Wide lattices of 2..5 bands go to grid3d_mbp_kernel (12-wave workgroups: compute waves + store waves around one
+    barrier per plane).  Edge bricks in x / y / z, slabs that do not start at plane 0, band counts, weights, first bands
+    and `s` cut-offs: every case against the bit-exact kernel (itself bit-identical to the oracle composition, checked
+    in test_multiband_grid_and_points) on the whole lattice, and two planes per case against the oracle itself."""
+    cases = [  # den, nx, ny, z0, z1, s, first, nbands, w
+        (512, 512, 24, 3, 14, -16.0, 0, 5, [1.0, 1.0, 1.0, 1.0, 1.0]),
+        (512, 516, 13, 0, 11, -16.0, 0, 5, [1.0, 0.5, 2.0, 1.0, 0.25]),     # partial bricks in x, y and z
+        (1024, 1024, 9, 5, 22, -16.0, 0, 5, [1.0, 1.0, 1.0, 1.0, 1.0]),    # two bricks in x, finer steps (K = 4 passes)
+        (512, 512, 17, 100, 109, -16.0, 0, 4, [0.5, 2.0, 1.0, 1.0]),
+        (512, 1028, 8, 0, 8, -16.0, 1, 3, [1.0, 0.5, 2.0]),                 # three bricks in x, the last one 4 samples wide
+        (512, 512, 8, 7, 9, -16.0, 2, 2, [1.0, 3.0]),
+        (512, 512, 10, 0, 9, -3.0, 0, 5, [1.0, 1.0, 1.0, 1.0, 1.0]),        # s + b < 0 stops after 3 bands, variance over 5
+        (768, 768, 16, 60, 70, -16.0, 0, 5, [1.0, 1.0, 1.0, 1.0, 1.0]),     # den not a power of two (division kept)
+    ]
+    for den, nx, ny, z0, z1, s, first, nb, w in cases:
+        fast = wn.multiband_volume(noise3, den, nx, ny, z0, z1, s, first, nb, w)
+        exact = wn.multiband_volume(noise3, den, nx, ny, z0, z1, s, first, nb, w, exact=True)
+        err = float((fast - exact).abs().max())
+        assert err <= TOL, (den, nx, ny, z0, z1, s, first, nb, err)
+        assert bool(torch.isfinite(fast).all())
+        for z in (z0, z1 - 1):
+            want = ora.grid_multiband3d_volume(tile3d_128, den, nx, ny, z, z + 1, s, first, nb, w, 0.18402)[0]
+            assert np.abs(host(fast[z - z0]) - want).max() <= TOL, (den, nx, ny, z)
+    # many bricks per workgroup, every workgroup busy: 512 x 512 x 40 planes = 1280 bricks on 256 CUs
+    fast = wn.multiband_volume(noise3, 512, 512, 512, 8, 48)
+    exact = wn.multiband_volume(noise3, 512, 512, 512, 8, 48, exact=True)
+    assert float((fast - exact).abs().max()) <= TOL
+    # output buffers handed in by the caller are written in place and nowhere else
+    buf = torch.full((512 * 512 * 10 + 64,), 7.0, dtype=torch.float32, device="cuda")
+    got = wn.multiband_volume(noise3, 512, 512, 512, 0, 10, out=buf)
+    assert torch.equal(got, wn.multiband_volume(noise3, 512, 512, 512, 0, 10))
+    assert bool((buf[512 * 512 * 10:] == 7.0).all())
+
+
+def test_full_512_cubed_multiband_volume_planes_and_properties(wn, ora, noise3, tile3d_128):
+    """BASELINE configs[2](A) at full size: the 512^3 x 5-band WMultibandNoise volume.  Three sampled planes against the
+    oracle's composition of evaluate3D calls (<= 1e-5), z-slabs computed separately bit-identical to the full call
+    (shard-safety), finite, mean ~ 0 and a standard deviation of ~ 0.77 (five independent bands of variance ~ 0.18402,
+    divided by sqrt(5 * 0.18402))."""
+    N = 512
+    vol = wn.multiband_volume(noise3, N, N, N, 0, N)
+    assert vol.shape == (N, N, N)
+    for z in (0, 301, 511):
+        want = ora.grid_multiband3d_volume(tile3d_128, N, N, N, z, z + 1, -16.0, 0, 5, [1.0] * 5, 0.18402)[0]
+        err = float(np.abs(host(vol[z]) - want).max())
+        assert err <= TOL, (z, err)
+    for z0, z1 in ((200, 208), (3, 30), (505, 512)):
+        part = wn.multiband_volume(noise3, N, N, N, z0, z1)
+        assert torch.equal(part, vol[z0:z1]), (z0, z1)
+    assert bool(torch.isfinite(vol).all())
+    assert abs(float(vol.double().mean())) < 2e-2
+    assert 0.6 < float(vol.std()) < 0.95
+    assert float(vol.abs().max()) < 5.0

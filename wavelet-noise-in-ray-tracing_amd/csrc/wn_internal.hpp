@@ -96,6 +96,11 @@ int check_handle_device(int handle_device, const char *what);
 // wn_wavelet_strip.hip: launches the strip-march kernel when the lattice is in its regime.
 int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_t stream, bool *launched);
 
+// wn_wavelet_multiband.hip: launches the plane-pipeline kernel when a multiband lattice is in its regime (g carries the
+// bands' common post_scale; oscale / weights per band; out_div = sqrt(sum w^2 * variance)).
+int multiband_try(const wn_tile *tile, const GridArgs &g, int nbands, const float *oscale, const float *weights,
+                  float out_div, float *out_dev, hipStream_t stream, bool *launched);
+
 // wn_wavelet_exact.hip: bit-exact dense 3-D grids with the coefficient box staged in LDS; *launched tells the caller.
 int exact_lds_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_t stream, bool *launched);
 

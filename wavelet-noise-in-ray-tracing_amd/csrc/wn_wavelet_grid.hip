@@ -875,6 +875,12 @@ int wn_multiband3d_grid(const wn_tile *tile, const wn_grid *grid, float s, int f
         size_t lds = 0;
         GridArgs gb = g;
         gb.post_scale = 2.0f;
+        {   // the plane-pipeline kernel (wn_wavelet_multiband.hip) takes wide lattices of 2..5 bands ...
+            bool launched = false;
+            rc = multiband_try(tile, gb, active, oscale, wts, out_div, out_dev, as_stream(stream), &launched);
+            if (rc || launched) return rc;
+        }
+        // ... the brick kernel the rest
         if (plan_sep(tile, gb, active, oscale, wts, out_div, &a, &lds)) {
             a.out = out_dev;
             a.vec4_ok = (g.nx % 4 == 0) && ((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0);
