@@ -300,7 +300,7 @@ class Workload:
             noise.generateNoiseTile3D()  # every rank regenerates the tile from the seed
             if wl == "multiband5":
                 self.step = lambda: wn.multiband_volume(noise, n, n, n, z0, z1, -16.0, 0, 5, out=self.out)
-                self.kernel, self.desc = "grid3d_sep_kernel<5", f"{slab} WMultibandNoise, 5 bands (configs[2])"
+                self.kernel, self.desc = "grid3d_mbp_kernel<5", f"{slab} WMultibandNoise, 5 bands (configs[2])"
             else:
                 exact = wl == "wavelet3d_exact"
                 self.step = wn.wavelet_volume_launcher(noise, n, n, n, z0, z1, OCTAVE, self.out, exact=exact)

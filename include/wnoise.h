@@ -218,9 +218,11 @@ WN_API int wn_noise_texture_points(const wn_perm *perm, double scale, int octave
  * (material.h:72, experient/main.cpp:28,56,85,104,122).  A kernel launch per call costs ~22 us; these
  * entry points hand the request to a resident one-wave kernel through a mailbox in pinned host memory
  * (csrc/wn_mailbox.hip): a few microseconds per call, results bit-identical to the batched entry points.
- * They block until the value is back and are serialised across host threads.  The resident kernel ends
- * by itself after 2 ms without a request (a device-wide synchronise never waits longer) and is restarted
- * by the next call. */
+ * They block until the value is back and are serialised across host threads per device.  The resident
+ * kernel ends by itself after 2 ms without a request, and after 20 ms in any case however many requests
+ * keep arriving: a device-wide synchronise from another thread (hipDeviceSynchronize, the hipFree inside
+ * wn_dev_free / wn_tile_destroy, torch.cuda.synchronize) never waits longer than ~20 ms, also in the middle
+ * of a burst of scalar calls.  The next call restarts it (one launch).  depth of kind 1 is 0..64. */
 WN_API int wn_scalar_eval3d(const wn_tile *tile3d, const float p[3], float *out);
 WN_API int wn_scalar_eval2d(const wn_tile *tile2d, const float p[2], float *out);
 WN_API int wn_scalar_eval3d_projected(const wn_tile *tile3d, const float p[3], const float normal[3],
@@ -234,6 +236,9 @@ WN_API int wn_scalar_noise_texture(const wn_perm *perm, double scale, int octave
                                    float *grey);
 /* Scalar calls served so far and resident-kernel instances started for them (diagnostics). */
 WN_API int wn_scalar_stats(unsigned long long *calls, unsigned long long *launches);
+/* Waits for the resident instances to end and releases the mailboxes (pinned host memory, streams);
+ * later scalar calls start over.  Optional: instances end by themselves. */
+WN_API int wn_scalar_shutdown(void);
 
 #ifdef __cplusplus
 }

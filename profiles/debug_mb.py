@@ -1,15 +1,16 @@
+"""Debug helper: which band of the plane-pipeline multiband kernel deviates from the bit-exact kernel."""
 import importlib, os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 wn = importlib.import_module("wavelet-noise-in-ray-tracing_amd")
-import oracle
 noise = wn.WaveletNoise(128, 12345); noise.generateNoiseTile3D()
-tile = oracle.tile3d(128, 12345)
-dbg = os.environ.get("WN_MBP_DEBUG", "0")
-got = wn.multiband_volume(noise, 512, 512, 8, 16, 20).cpu().numpy()
-want = oracle.grid_multiband3d_volume(tile, 512, 512, 8, 16, 20, -16.0, 0, 5, [1.0]*5, 0.18402)
-print("debug", dbg, "got[0,0,:8]", got[0,0,:8], "got[1,3,100:104]", got[1,3,100:104], "nonzero", np.count_nonzero(got), got.size)
-if dbg == "0":
-    print("want[0,0,:8]", want[0,0,:8], "maxerr", np.abs(got-want).max())
-if dbg == "2":
-    # c[0] of the top band's first pass: tile[(kz0)&127][(jy0)&127][(ix0 + col)&127]
-    print("tile[0..]", tile.reshape(128,128,128)[:2,:2,:6])
+for (ny, z0, z1) in ((8, 16, 20), (24, 0, 24)):
+    for k in range(5):
+        w = [0.0] * 5; w[k] = 1.0
+        fast = wn.multiband_volume(noise, 512, 512, ny, z0, z1, -16.0, 0, 5, w)
+        exact = wn.multiband_volume(noise, 512, 512, ny, z0, z1, -16.0, 0, 5, w, exact=True)
+        err = (fast - exact).abs()
+        bad = (err > 1e-5).nonzero()
+        print("ny", ny, "z", z0, z1, "band", k, "max err", float(err.max()), "bad count", bad.shape[0],
+              "first bad (z,y,x)", bad[0].tolist() if bad.shape[0] else None,
+              "bad planes", sorted(set(bad[:, 0].tolist()))[:10] if bad.shape[0] else None,
+              "bad rows", sorted(set(bad[:, 1].tolist()))[:10] if bad.shape[0] else None)

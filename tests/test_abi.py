@@ -83,3 +83,35 @@ def test_package_import_fails_loudly_without_library(tmp_path, capi):
     )
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert "RAISED True" in out.stdout, out.stdout + out.stderr
+
+
+# ---- libwnoise_shard.so (include/wnoise_shard.h): the gather of the sharded dense-grid path over RCCL ----------------------
+def shard_declared_symbols():
+    text = open(os.path.join(ROOT, "include", "wnoise_shard.h")).read()
+    return sorted(set(re.findall(r"WN_SHARD_API\s+[\w\s\*]+?\b(wn_\w+)\s*\(", text)))
+
+
+def test_shard_header_symbols_all_exported_and_bound_and_bounds_match_python():
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ROOT, PKG, "libwnoise_shard.so")):
+        ge.build()
+    cs = importlib.import_module(PKG + "._capi_shard")
+    lib = cs.load()  # links librccl: present in the image, needs no GPU to load
+    names = shard_declared_symbols()
+    assert len(names) == 7, names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/wnoise_shard.h but not exported"
+    assert set(cs.SIGNATURES) == set(names)
+    wn = importlib.import_module(PKG)
+    for nz, world in ((2048, 8), (512, 3), (7, 4), (0, 2), (5, 8)):
+        seen = 0
+        for r in range(world):
+            z0, z1 = C.c_int(-1), C.c_int(-1)
+            assert lib.wn_shard_bounds(nz, world, r, C.byref(z0), C.byref(z1)) == 0
+            assert (z0.value, z1.value) == wn.slab_bounds(nz, world, r)  # the C ABI and shard.py cut the same slabs
+            assert z0.value == seen
+            seen = z1.value
+        assert seen == nz
+    z0, z1 = C.c_int(), C.c_int()
+    assert lib.wn_shard_bounds(8, 2, 2, C.byref(z0), C.byref(z1)) != 0 and b"rank=2" in lib.wn_shard_last_error()
+    assert lib.wn_gather_volume(None, None, 8, 8, 8, 0, None, 0, None) != 0  # NULL communicator is refused, not dereferenced

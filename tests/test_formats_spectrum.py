@@ -108,3 +108,8 @@ def test_converter_size_mismatch_and_missing_input_follow_the_reference(fm, tmp_
     assert doc["original_range"]["max"] == 4095.0 and doc["data"][-1] == 1.0
     np.arange(50, dtype=np.float32).tofile(tmp_path / "ragged.raw")
     assert fm.convert_raw_to_json(str(tmp_path / "ragged.raw"), str(tmp_path / "ragged.json"), 256) is False
+    # a file whose length is no multiple of 4: the reference's struct.unpack raises (:30-33) and it returns False (:88-90)
+    with open(tmp_path / "trailing.raw", "wb") as f:
+        f.write(np.arange(64 * 64, dtype=np.float32).tobytes() + b"\x01\x02")
+    assert fm.convert_raw_to_json(str(tmp_path / "trailing.raw"), str(tmp_path / "trailing.json"), 64) is False
+    assert not (tmp_path / "trailing.json").exists()

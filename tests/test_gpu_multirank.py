@@ -79,6 +79,47 @@ def test_bench_launches_its_own_ranks_two_gloo_ranks_on_one_gpu():
     assert 0 < ss["efficiency"] < 1.5  # two ranks sharing ONE GPU: ~0.5; the key exists and is sane
 
 
+def test_native_gather_world_size_one_identity_and_two_forked_ranks_when_two_gpus(wn):
+    """The C ABI's gather (include/wnoise_shard.h, libwnoise_shard.so: ncclCommInitRank + one grouped ncclSend / ncclRecv).
+    On a one-GPU box: a communicator of world size 1 is created over RCCL and the gather is the identity (the root's own
+    slab lands in its place by a device copy), in place and out of place, with a piece size that cuts the slab into
+    several pieces.  The N > 1 leg of the same entry point is tools/gridgen --gpus N (unmeasured on hardware: one-GPU lease)."""
+    noise = wn.WaveletNoise(128, 12345)
+    noise.generateNoiseTile3D()
+    slab = wn.wavelet_volume(noise, 256, 256, 256, 0, 24, 4).clone()
+    comm = wn.NativeComm(world=1, rank=0, id_bytes=wn.NativeComm.unique_id())
+    try:
+        out = torch.full((24, 256, 256), -7.0, dtype=torch.float32, device="cuda")
+        full = comm.gather_volume(slab, 24, dst=0, out=out, piece_bytes=5 * 256 * 256 * 4)
+        torch.cuda.synchronize()
+        assert full.data_ptr() == out.data_ptr() and torch.equal(full, slab)
+        again = comm.gather_volume(slab, 24, dst=0)  # fresh output buffer
+        torch.cuda.synchronize()
+        assert torch.equal(again, slab)
+        same = comm.gather_volume(slab, 24, dst=0, out=slab)  # the slab already is the volume: nothing to copy
+        assert same.data_ptr() == slab.data_ptr()
+    finally:
+        comm.close()
+
+
+def test_gridgen_shards_a_lattice_over_one_rank_with_the_native_gather(tmp_path):
+    """tools/gridgen --gpus 1 --lattice 256: the C++ grid generator's sharded mode (fresh child per rank, the parent never
+    touches a GPU) through wn_comm_create / wn_gather_volume; the gathered volume's planes are the plain call's."""
+    exe = os.path.join(ROOT, "wavelet-noise-in-ray-tracing_amd", "tools", "gridgen")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    out = subprocess.run([exe, str(tmp_path), "--gpus", "1", "--lattice", "256", "--octave", "4"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["lattice"] == 256 and line["ranks"] == 1 and line["gathered_planes"] == 256
+    vol = np.fromfile(tmp_path / "wavelet_noise_3D_lattice_256_octave_4_plane_0.raw", dtype="<f4")
+    wnm = importlib.import_module("wavelet-noise-in-ray-tracing_amd")
+    noise = wnm.WaveletNoise(128, 12345)
+    noise.generateNoiseTile3D()
+    want = wnm.wavelet_volume(noise, 256, 256, 256, 0, 1, 4)[0].cpu().numpy().ravel()
+    assert (bits(vol) == bits(want)).all()
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL gather needs two GPUs")
 def test_gather_volume_on_rccl_two_gpus():
     """Two ranks, one per GPU, nccl (= RCCL) backend: bench.py's sharded run gathers the slabs on rank 0 and checks

@@ -48,3 +48,26 @@ def test_batched_render_equals_the_committed_image(tmp_path, art, noise, name):
     head = open(tmp_path / "img.ppm").read(20)
     assert head.startswith("P3\n1000 500\n255\n")  # main.cpp:172
     print(out.stdout.strip())
+
+
+@pytest.mark.gpu
+def test_config3_size_stream_1920x1080_spp64_first_values_bit_equal_to_the_oracle(tmp_path):
+    """BASELINE configs[3] at its stated size: the batched renderer at 1920 x 1080, spp 64, wavelet noise_texture, octave 4.
+    The whole hit-point stream (> 7e7 texture evaluations, scanline order, every bounce) goes through the plane-ordered
+    chunk kernel band by band; the first 131,072 values are compared bit for bit with the oracle's restatement of
+    wavelet_texture::value (texture.h:67-107) on the same points, and the kernel is timed alone on the stream."""
+    import numpy as np
+    import oracle
+    dump = tmp_path / "first.bin"
+    out = subprocess.run([EXE, "--width", "1920", "--height", "1080", "--spp", "64", "--noise", "1", "--octave", "4",
+                          "--time-kernel", "--dump-first", "131072", str(dump)], capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout + out.stderr
+    import re
+    m = re.search(r"(\d+) noise evaluations", out.stdout)
+    assert m and int(m.group(1)) > 7 * 10 ** 7, out.stdout
+    rec = np.fromfile(dump, dtype="<f4").reshape(-1, 4)
+    assert rec.shape[0] == 131072
+    want = oracle.wavelet_texture_value(oracle.tile3d(128, 12345), True, 1.0, 4, np.ascontiguousarray(rec[:, :3]))
+    assert (rec[:, 3].view(np.uint32) == want.view(np.uint32)).all()
+    assert "G points/s" in out.stdout
+    print(out.stdout.strip())

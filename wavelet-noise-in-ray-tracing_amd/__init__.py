@@ -23,7 +23,7 @@ from .noise import (  # noqa: E402
     generate3DProjectedOctaveBandNoise, generatePerlinNoise2D, generatePerlinNoise3DSliced,
     wavelet_volume, wavelet_volume_launcher, multiband_volume, perlin_volume, turb_volume, device_info, HipTimer,
 )
-from .shard import slab_bounds, gather_volume  # noqa: E402
+from .shard import slab_bounds, gather_volume, NativeComm  # noqa: E402
 from . import formats  # noqa: E402
 
 __all__ = [
@@ -32,5 +32,5 @@ __all__ = [
     "generate2DOctaveBandNoise", "generate3DSlicedOctaveBandNoise",
     "generate3DProjectedOctaveBandNoise", "generatePerlinNoise2D", "generatePerlinNoise3DSliced",
     "wavelet_volume", "wavelet_volume_launcher", "multiband_volume", "perlin_volume", "turb_volume", "device_info",
-    "HipTimer", "slab_bounds", "gather_volume", "formats",
+    "HipTimer", "slab_bounds", "gather_volume", "NativeComm", "formats",
 ]

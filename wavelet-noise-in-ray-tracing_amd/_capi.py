@@ -92,6 +92,7 @@ SIGNATURES = {
     "wn_scalar_wavelet_texture": (_i, [_vp, _i, _d, _i, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "wn_scalar_noise_texture": (_i, [_vp, _d, _i, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "wn_scalar_stats": (_i, [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "wn_scalar_shutdown": (_i, []),
 }
 
 _lib = None

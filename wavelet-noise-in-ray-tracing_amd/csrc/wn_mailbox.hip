@@ -8,9 +8,11 @@
 // use (wn_device_eval.hpp / wn_texture_eval.hpp -> bit-identical results), and writes value and
 // sequence number back.  A call is two PCIe round trips plus the evaluation.
 //
-// The kernel is not immortal: after kIdleTicks without a request it marks the mailbox STOPPED and
-// exits, so a device-wide synchronise never waits longer than that and nothing is left spinning when
-// the process ends; the next scalar call starts a fresh instance (one ordinary launch).  A request
+// The kernel is not immortal: after kIdleTicks (2 ms) without a request, or kLifeTicks (20 ms) after its start
+// however many requests keep arriving, it marks the mailbox STOPPED and exits -- so a device-wide synchronise
+// (hipDeviceSynchronize, a hipFree inside wn_dev_free / wn_tile_destroy, torch.cuda.synchronize) issued by another
+// thread in the middle of a burst of scalar calls never waits longer than ~20 ms, and nothing is left spinning when
+// the process ends; the next scalar call starts a fresh instance (one ordinary launch, ~15 us every 20 ms).  A request
 // posted while an instance is timing out is never lost: the host re-launches when it sees STOPPED with
 // its request unanswered, and an instance starts from the last ANSWERED sequence number.
 #include "wn_internal.hpp"
@@ -29,7 +31,8 @@ enum : uint32_t {
     kOpEval3d = 1, kOpEval2d, kOpProjected, kOpPerlin, kOpPerlinVec3, kOpWaveletTexture, kOpNoiseTexture
 };
 enum : uint32_t { kStopped = 0, kRunning = 1 };
-constexpr unsigned long long kIdleTicks = 200000ull; // wall_clock64() ticks at 100 MHz: 2 ms
+constexpr unsigned long long kIdleTicks = 200000ull;  // wall_clock64() ticks at 100 MHz: 2 ms without a request
+constexpr unsigned long long kLifeTicks = 2000000ull; // ... and 20 ms in all, however busy: see the kernel
 
 // One 64-byte line: the host fills everything, then stores `seq` (release).  The device reads the line
 // with one wave-wide load and acts only when `seq` moved.
@@ -42,8 +45,10 @@ struct alignas(64) Request {
         double d[4];
     } a;            // points, normals, scales
     int32_t aux;    // texture mode / perlin kind / padded-tile flag
-    uint32_t check; // xor of the 15 other dwords: a line that arrives torn (sequence number ahead of the
-                    // arguments) does not verify and is simply polled again
+    uint32_t check; // makes the xor of the 16 dwords, each ROTATED LEFT BY ITS INDEX, zero: a line that arrives torn
+                    // (sequence number ahead of the arguments) does not verify and is simply polled again.  The rotation
+                    // makes the test position-dependent: with a plain xor, stale dwords whose old ^ new differences cancel
+                    // (evaluate2D walked along the diagonal: dwords 4 and 5 change alike) would verify under the new seq.
     uint64_t seq;
 };
 static_assert(sizeof(Request) == 64, "one line");
@@ -111,13 +116,14 @@ __global__ __launch_bounds__(64) void mailbox_kernel(const uint32_t *req, Respon
 {
     const int lane = threadIdx.x;
     unsigned long long idle_since = wall_clock64();
+    const unsigned long long born = idle_since;
     for (;;) {
         // the request line in one wave-wide load: lanes 0..15 take one dword each, bypassing the caches
         uint32_t word = 0;
         if (lane < 16) word = __hip_atomic_load(req + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long seq = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)word, 14) |
                                        ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)word, 15) << 32);
-        uint32_t fold = word; // xor over lanes 0..15 (the other lanes hold 0): 0 when the line verifies
+        uint32_t fold = (word << (lane & 15)) | (word >> ((32 - (lane & 15)) & 31)); // rotl by the dword's index; lanes >= 16 hold 0
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) fold ^= (uint32_t)__shfl_xor((int)fold, off, 64);
         if (seq != last_seq && __builtin_amdgcn_readfirstlane((int)fold) == 0) {
@@ -132,6 +138,9 @@ __global__ __launch_bounds__(64) void mailbox_kernel(const uint32_t *req, Respon
                 __hip_atomic_store(&resp->seq, (uint64_t)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             idle_since = wall_clock64();
+            // a busy instance ends too (round-2 ADVICE: one thread's burst of scalar calls must not hold up another
+            // thread's device-wide synchronise for the length of the burst); the host starts the next one
+            if (idle_since - born > kLifeTicks) break;
         } else {
             if (wall_clock64() - idle_since > kIdleTicks) break; // every instance ends: nothing spins for ever
             __builtin_amdgcn_s_sleep(2);
@@ -150,9 +159,11 @@ struct Mailbox {
     hipStream_t stream = nullptr;
     uint64_t seq = 0;
     unsigned long long launches = 0;
+    bool failed = false; // a request timed out: later calls fail at once until the instance reports STOPPED
+    std::mutex mu;       // scalar calls on one device are serialised; devices do not wait for each other
 };
 
-std::mutex g_mu;
+std::mutex g_mu; // guards the map only
 std::map<int, Mailbox *> g_boxes;
 
 int create_box(int device, Mailbox **out)
@@ -200,24 +211,36 @@ int start_instance(Mailbox *b)
     return WN_OK;
 }
 
-// Post one request and wait for its answer.  Scalar calls of all threads are serialised here.
+// Post one request and wait for its answer.  Scalar calls of all threads on one device are serialised here.
 int call(int device, Request &r, double *value)
 {
-    std::lock_guard<std::mutex> lock(g_mu);
     int rc = wn::require_device();
     if (rc) return rc;
     if (wn::current_device() != device) return wn::fail(WN_ERR_INVALID, "handle lives on device %d, current device is %d", device, wn::current_device());
     Mailbox *b = nullptr;
-    auto it = g_boxes.find(device);
-    if (it != g_boxes.end()) b = it->second;
-    else if ((rc = create_box(device, &b)) != WN_OK) return rc;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        auto it = g_boxes.find(device);
+        if (it != g_boxes.end()) b = it->second;
+        else if ((rc = create_box(device, &b)) != WN_OK) return rc;
+    }
+    std::lock_guard<std::mutex> lock(b->mu);
+    if (b->failed) { // an earlier request never came back: do not spin another 10 s behind it
+        if (__atomic_load_n(b->state, __ATOMIC_ACQUIRE) != kStopped)
+            return wn::fail(WN_ERR_HIP, "scalar mailbox: the resident kernel did not answer an earlier request and is still busy");
+        b->failed = false;
+    }
 
     const uint64_t seq = ++b->seq;
     r.seq = seq;
     r.check = 0;
     uint32_t fold = 0;
-    for (int i = 0; i < 16; ++i) fold ^= reinterpret_cast<const uint32_t *>(&r)[i];
-    r.check = fold; // the xor of all 16 dwords is now 0
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t w = reinterpret_cast<const uint32_t *>(&r)[i];
+        fold ^= (w << i) | (w >> ((32 - i) & 31));
+    }
+    constexpr int kCheckIndex = offsetof(Request, check) / 4;
+    r.check = (fold >> kCheckIndex) | (fold << ((32 - kCheckIndex) & 31)); // rotr: the rotated xor of all 16 dwords is now 0
     std::memcpy(b->req, &r, offsetof(Request, seq));           // everything but the sequence number ...
     __atomic_store_n(&b->req->seq, seq, __ATOMIC_RELEASE);     // ... which goes last
     if (__atomic_load_n(b->state, __ATOMIC_ACQUIRE) != kRunning && (rc = start_instance(b)) != WN_OK) return rc;
@@ -231,8 +254,10 @@ int call(int device, Request &r, double *value)
         }
         __builtin_ia32_pause();
         if ((++spins & 0xfffff) == 0 &&
-            std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
+            std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
+            b->failed = true;
             return wn::fail(WN_ERR_HIP, "scalar mailbox: no answer from the device within 10 s");
+        }
     }
     *value = b->resp->value;
     return WN_OK;
@@ -325,7 +350,8 @@ int wn_scalar_perlin_vec3(const wn_perm *perm, const float p[3], int kind, int d
 {
     WN_ENTRY();
     if (!perm || !p || !out) return fail(WN_ERR_INVALID, "wn_scalar_perlin_vec3: NULL argument");
-    if (kind < 0 || kind > 2 || depth < 0) return fail(WN_ERR_INVALID, "wn_scalar_perlin_vec3: bad kind/depth");
+    if (kind < 0 || kind > 2 || depth < 0 || depth > 64) // 64 octaves reach past double precision; keeps one request bounded
+        return fail(WN_ERR_INVALID, "wn_scalar_perlin_vec3: kind must be 0..2 and depth 0..64");
     Request r{};
     r.op = kOpPerlinVec3;
     r.aux = kind;
@@ -378,6 +404,23 @@ int wn_scalar_noise_texture(const wn_perm *perm, double scale, int octave, const
     int rc = call(perm->device, r, &v);
     *grey = (float)v;
     return rc;
+}
+
+int wn_scalar_shutdown(void)
+{
+    // Ends every resident instance and releases the mailboxes (pinned memory, streams).  Instances end by themselves
+    // within kIdleTicks of the last request; this waits for that.  Later scalar calls start over.
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (auto &kv : g_boxes) {
+        Mailbox *b = kv.second;
+        std::lock_guard<std::mutex> box_lock(b->mu);
+        (void)hipStreamSynchronize(b->stream);
+        (void)hipStreamDestroy(b->stream);
+        (void)hipHostFree(b->req);
+    }
+    for (auto &kv : g_boxes) delete kv.second;
+    g_boxes.clear();
+    return WN_OK;
 }
 
 int wn_scalar_stats(unsigned long long *calls, unsigned long long *launches)

@@ -42,6 +42,7 @@ namespace {
 using wn::GridArgs;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int kMaxNB = 5;                  // bands this kernel is instantiated for (more: the brick kernel)
 constexpr int kWW = 8, kPW = 4, kSW = 4;   // window / collapse / store waves per workgroup
@@ -55,7 +56,7 @@ constexpr int kRRow = kPasses * 64;        // R: [plane slot][row of samples][pa
 constexpr int kRPlane = kBY * kRRow;       // floats per R plane slot (16 KiB)
 constexpr int kRingFloats = kRing * kBY * kBX;
 constexpr int kBoxFloats = 6144;           // LDS-DMA landing zone (24 KiB): the boxes of all bands of one brick
-constexpr int kDmaPlanes = 4;              // the next brick's box rows are requested over this many planes ...
+constexpr int kDmaPlanes = kMaxNB;         // the next brick's box rows are requested band by band over the first planes ...
 constexpr int kDmaLanded = kBZ - 2;        // ... and are complete at the end of this plane's iteration
 
 struct MbBand {
@@ -116,6 +117,11 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
     __shared__ __attribute__((aligned(16))) float s_box[kBoxFloats]; // LDS-DMA landing zone: per band [(k, j) row][column]
     __shared__ int s_mid[3][NB][32];
     __shared__ float s_w[3][NB][kSlotX][3];
+    __shared__ float s_oscale[NB];
+    // derived per brick and band by the store waves an iteration before the collapse waves need them:
+    __shared__ __attribute__((aligned(16))) float s_wy[NB][kMaxK][kBY]; // zero-padded y weights x the band's factor: [box row j][row of samples]
+    __shared__ float s_wz[NB][64];                                      // zero-padded z weights dealt to register slots: [plane*8 + slot]
+    __shared__ int s_prep[NB][4];                                       // {slot of the box's first row, fresh rows, first column & 3, -}
     __shared__ int s_bandc[NB][4]; // {K, box_off, rowlen, first_pass}: read with ds_read, not reloaded from the kernel arguments
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -124,7 +130,8 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
     const GridArgs &g = a.g;
     float *const ring = lds + 2 * kRPlane;
 
-    // bricks: id = bx * (nby*nbz) + bz * nby + by; each workgroup owns a contiguous range (bx mostly fixed)
+    // bricks: id = (bx * nby + by) * nbz + bz; each workgroup owns a contiguous range and marches along z: consecutive
+    // bricks mostly share their column (bx, by), so a band's coefficient box only moves by 0..2 rows in z between them
     const int nyz = a.nby * a.nbz;
     const long long total = (long long)a.nbx * nyz;
     const int item0 = (int)(total * blockIdx.x / gridDim.x), item1 = (int)(total * (blockIdx.x + 1) / gridDim.x);
@@ -136,28 +143,29 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
     auto brick_of = [&](int item) {
         Brick k;
         k.bx = item / nyz;
-        k.bz = (item - k.bx * nyz) / a.nby;
-        k.by = item - k.bx * nyz - k.bz * a.nby;
+        k.by = (item - k.bx * nyz) / a.nbz;
+        k.bz = item - k.bx * nyz - k.by * a.nbz;
         return k;
     };
     auto advance = [&](Brick &k) {
-        if (++k.by == a.nby) { k.by = 0; ++k.bz; }
-        if (k.bz == a.nbz) { k.bz = 0; ++k.bx; }
+        if (++k.bz == a.nbz) { k.bz = 0; ++k.by; }
+        if (k.by == a.nby) { k.by = 0; ++k.bx; }
     };
 
     // per-band sample tables of a brick (threads of the first window waves): mids and B-spline weights of its 8 rows,
     // 8 planes and first / last x sample, computed exactly as the reference does per sample
     auto fill_tables = [&](int buf, const Brick &k) {
-        const int b = tid >> 5, slot = tid & 31;
+        int tt = tid;
+        asm volatile("" : "+v"(tt)); // what derives from it is computed here, not kept in (spilled) registers across the loop
+        const int b = tt >> 5, slot = tt & 31;
         if (b < NB && slot < kSlotX + 2) {
             int idx;
             if (slot < kSlotZ) idx = min(k.by * kBY + slot, g.ny - 1);
             else if (slot < kSlotX) idx = g.z0 + min(k.bz * kBZ + slot - kSlotZ, g.nz - 1);
             else idx = (slot == kSlotX) ? k.bx * kBX : min(k.bx * kBX + kBX - 1, g.nx - 1);
-            float oscale = a.band[0].oscale;
-#pragma unroll
-            for (int bb = 1; bb < NB; ++bb) oscale = (b == bb) ? a.band[bb].oscale : oscale;
-            const float c = coord_of(idx, (float)g.den, a.inv_den, g.base_range, oscale, g.post_scale);
+            // (the band's scale from LDS: indexed by a lane value the kernel argument becomes a vector-memory load, which in
+            // this kernel would queue behind the store waves' stores)
+            const float c = coord_of(idx, (float)g.den, a.inv_den, g.base_range, s_oscale[b], g.post_scale);
             int m;
             float w0, w1, w2;
             wn::bspline(c, m, w0, w1, w2);
@@ -170,13 +178,59 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
         }
     };
     auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    // Box rows in z that band b needs FRESH for brick B (tables tB) when brick A (tables tA) was the previous one of this
+    // workgroup: in the same column the box moved up by d = 0, 1 or 2 rows and keeps its other rows (the collapse waves shift
+    // their registers); anything else -- another column, a larger move, the first brick -- is a whole box, d = K.
+    // Both the store waves (what to request) and the collapse waves (what to shift) derive it from the same tables.
+    auto fresh_rows = [&](int b, int K, int tA, int tB, bool same_column) {
+        const int d = sgpr(s_mid[tB][b][kSlotZ]) - sgpr(s_mid[tA][b][kSlotZ]);
+        return (same_column && d >= 0 && d <= 2) ? d : K;
+    };
+
+    // One wave per band b (a store wave: few live registers, time to spare), for the brick with tables tB that follows the
+    // brick with tables tA:
+    //  * s_wz[b][plane*8 + slot]: the K box rows in z live in K register slots of the collapse waves as a ring -- tile row
+    //    kabs sits in slot kabs mod K, so the rows a brick keeps from its predecessor stay where they are and the z weights
+    //    are dealt to the slots instead;  * s_wy[b][j][yi]: zero-padded y weights with the band's factor folded in;
+    //  * s_prep[b]: the slot of the box's first row, how many of its top rows are fresh, its first column modulo 4.
+    auto derive_tables = [&](int b, int tA, int tB, bool same_column, bool first) {
+        const int l = lane;
+        {
+            const int K = s_bandc[b][0];
+            const int kz0 = s_mid[tB][b][kSlotZ] - 1;
+            // K is 4 or 5: the two modulos by cases (a division by a run-time K is ~30 instructions)
+            const int kzm = (K == 4) ? (kz0 & 3) : ((kz0 + 20 * 65536) % 5); // slot of the box's first row
+            {
+                const int zi = l >> 3, slot = l & 7;
+                int tau = slot - kzm + K; // box row (0 = first) held by `slot`: (slot - kzm) mod K, operand in [1, 2K+2]
+                if (K == 4) tau &= 3;
+                else tau -= (tau >= 10) ? 10 : (tau >= 5 ? 5 : 0);
+                const int dd = tau - (s_mid[tB][b][kSlotZ + zi] - s_mid[tB][b][kSlotZ]);
+                const float w0 = s_w[tB][b][kSlotZ + zi][0], w1 = s_w[tB][b][kSlotZ + zi][1], w2 = s_w[tB][b][kSlotZ + zi][2];
+                s_wz[b][l] = (slot < K && (unsigned)dd <= 2u) ? (dd == 0 ? w0 : dd == 1 ? w1 : w2) : 0.0f;
+            }
+            if (l < kMaxK * kBY) {
+                const int j = l >> 3, yi = l & 7;
+                const int dd = j - (s_mid[tB][b][yi] - s_mid[tB][b][0]);
+                const float w0 = s_w[tB][b][yi][0], w1 = s_w[tB][b][yi][1], w2 = s_w[tB][b][yi][2];
+                float f = a.band[0].factor;
+#pragma unroll
+                for (int bb = 1; bb < NB; ++bb) f = (b == bb) ? a.band[bb].factor : f;
+                s_wy[b][j][yi] = ((unsigned)dd <= 2u ? (dd == 0 ? w0 : dd == 1 ? w1 : w2) : 0.0f) * f;
+            }
+            if (l == 0) {
+                const int dz = s_mid[tB][b][kSlotZ] - s_mid[tA][b][kSlotZ];
+                s_prep[b][0] = kzm;
+                s_prep[b][1] = (!first && same_column && dz >= 0 && dz <= 2) ? dz : K;
+                s_prep[b][2] = (s_mid[tB][b][kSlotX] - 1) & 3;
+            }
+        }
+    };
 
     Brick cur = brick_of(item0), nxt = cur;
     advance(nxt);
     Brick nxt2 = nxt;
     advance(nxt2);
-    fill_tables(0, cur);
-    if (nb > 1) fill_tables(1, nxt);
     if (tid < NB) {
         int K = a.band[0].K, box_off = a.band[0].box_off, rowlen = a.band[0].rowlen, fp = a.band[0].first_pass;
 #pragma unroll
@@ -190,7 +244,14 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
         s_bandc[tid][1] = box_off;
         s_bandc[tid][2] = rowlen;
         s_bandc[tid][3] = fp;
+        float os = a.band[0].oscale;
+#pragma unroll
+        for (int bb = 1; bb < NB; ++bb) os = (tid == bb) ? a.band[bb].oscale : os;
+        s_oscale[tid] = os;
     }
+    __syncthreads();
+    fill_tables(0, cur);
+    if (nb > 1) fill_tables(1, nxt);
     __syncthreads();
     int tb = 0, t = 0; // table buffer and index of the current brick
     auto next_brick = [&]() {
@@ -229,40 +290,39 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
             for (int bb = 1; bb < NB; ++bb) f = (bb0 == bb) ? a.band[bb].factor : f;
             P.factor = __int_as_float(sgpr(__float_as_int(f)));
         }
-        // The box has landed: the lane's K x K column comes out of the DMA zone and is collapsed in y ONCE per brick --
+        // The box has landed: the lane's column comes out of the DMA zone and is collapsed in y ONCE per brick --
         // yc[yi][k] = sum_j wy[yi][j] * c[k][j] (the band's factor folded in), weights zero-padded to the box and uniform
-        // (v_readlane -> SGPR operand, each feeding K independent FMAs), one box row in y at a time (K coefficients
-        // live beside the 8 x K results) -- so that a plane costs 8 x K FMAs with K uniform z weights.  (First version:
-        // z then y per plane, 8 x K readlane-fed dependent FMAs per plane: 4,000-5,600 cycles a plane by the time stamps.)
+        // (v_readlane -> SGPR operand), one box row in y at a time -- so that a plane costs 8 x K FMAs with K uniform z
+        // weights.  (First version: z then y per plane, 8 x K readlane-fed dependent FMAs per plane: 4,000-5,600 cycles a
+        // plane by the time stamps.)  Marching along z, brick t+1's box is brick t's moved up by d rows: the rows it keeps
+        // stay in their registers, only the d fresh rows are collapsed (whole boxes cost ~4,400 cycles of the brick's last
+        // plane and 89 DMA requests a brick; at 512^3 x 5 bands d = 2 of 5 rows for the top band, <= 1 of 4 below).
         // wzv: lane (zi*8 + tap) = zero-padded z weight of plane zi at box row tap.
-        auto prep_brick = [&](const Pass &P, int tbuf, auto &yc, float &wzv, auto kc) {
+        auto prep_brick = [&](const Pass &P, auto &yc, float &wzv, auto kc) {
             constexpr int K = decltype(kc)::value;
             if constexpr (K > 0) {
-                const int idx = lane >> 3, tap = lane & 7;
-                float wyv;
-                {
-                    const int d = tap - (s_mid[tbuf][P.band][idx] - s_mid[tbuf][P.band][0]);
-                    const float *w = s_w[tbuf][P.band][idx];
-                    wyv = (d == 0 ? w[0] : d == 1 ? w[1] : d == 2 ? w[2] : 0.0f) * P.factor;
-                }
-                {
-                    const int d = tap - (s_mid[tbuf][P.band][kSlotZ + idx] - s_mid[tbuf][P.band][kSlotZ]);
-                    const float *w = s_w[tbuf][P.band][kSlotZ + idx];
-                    wzv = d == 0 ? w[0] : d == 1 ? w[1] : d == 2 ? w[2] : 0.0f;
-                }
+                const int kzm = sgpr(s_prep[P.band][0]), d = sgpr(s_prep[P.band][1]);
+                wzv = s_wz[P.band][lane];
                 // (lanes past the box's last column -- their R columns are never read -- stay inside the row image)
-                const float *img = s_box + P.box_off +
-                                   min(((sgpr(s_mid[tbuf][P.band][kSlotX]) - 1) & 3) + P.col0 + lane, P.rowlen - 1);
+                const float *img = s_box + P.box_off + min(sgpr(s_prep[P.band][2]) + P.col0 + lane, P.rowlen - 1);
+                // the box's top d rows are fresh: the DMA zone holds them as image rows (f, j), f = 0..d-1
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    float cj[K];
+                for (int sl = 0; sl < K; ++sl) {
+                    const int tau = (sl - kzm + K) % K;
+                    if (tau >= K - d) { // wave-uniform
+                        const float *row = img + (tau - (K - d)) * K * P.rowlen;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) cj[k] = img[(k * K + j) * P.rowlen];
+                        for (int j = 0; j < K; ++j) {
+                            const float cj = row[j * P.rowlen];
+                            const v2f c2 = {cj, cj};
 #pragma unroll
-                    for (int yi = 0; yi < kBY; ++yi) {
-                        const float w = readlane_f(wyv, yi * 8 + j);
-#pragma unroll
-                        for (int k = 0; k < K; ++k) yc[yi][k] = (j == 0) ? w * cj[k] : __builtin_fmaf(w, cj[k], yc[yi][k]);
+                            for (int h = 0; h < 2; ++h) { // a box row's 8 weights: two broadcast ds_read_b128 into VGPRs
+                                const v4f w4 = *reinterpret_cast<const v4f *>(&s_wy[P.band][j][4 * h]);
+                                const v2f wlo = {w4.x, w4.y}, whi = {w4.z, w4.w};
+                                yc[2 * h][sl] = (j == 0) ? wlo * c2 : __builtin_elementwise_fma(wlo, c2, yc[2 * h][sl]);
+                                yc[2 * h + 1][sl] = (j == 0) ? whi * c2 : __builtin_elementwise_fma(whi, c2, yc[2 * h + 1][sl]);
+                            }
+                        }
                     }
                 }
             }
@@ -275,11 +335,12 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
 #pragma unroll
                 for (int k = 0; k < K; ++k) wz[k] = readlane_f(wzv, zi * 8 + k);
 #pragma unroll
-                for (int yi = 0; yi < kBY; ++yi) {
-                    float v = wz[0] * yc[yi][0];
+                for (int p2 = 0; p2 < kBY / 2; ++p2) { // rows of samples in pairs: v_pk_fma_f32, the weight a scalar splat
+                    v2f v = v2f{wz[0], wz[0]} * yc[p2][0];
 #pragma unroll
-                    for (int k = 1; k < K; ++k) v = __builtin_fmaf(wz[k], yc[yi][k], v);
-                    Rw[yi * kRRow] = v;
+                    for (int k = 1; k < K; ++k) v = __builtin_elementwise_fma(v2f{wz[k], wz[k]}, yc[p2][k], v);
+                    Rw[(2 * p2) * kRRow] = v.x;
+                    Rw[(2 * p2 + 1) * kRRow] = v.y;
                 }
             }
         };
@@ -287,12 +348,12 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
         // no joins between K variants inside the loop.
         auto collapse_role = [&](auto k0c, auto k1c) {
             constexpr int K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
-            float yc0[kBY][K0 > 0 ? K0 : 1], yc1[kBY][K1 > 0 ? K1 : 1];
+            v2f yc0[kBY / 2][K0 > 0 ? K0 : 1], yc1[kBY / 2][K1 > 0 ? K1 : 1]; // [pair of rows of samples][slot]
             float wzv0 = 0.0f, wzv1 = 0.0f;
             float *const Rw0 = lds + 64 * ps[0].id + lane, *const Rw1 = lds + 64 * ps[1].id + lane;
             lds_barrier(); // the store waves' requests for the first brick's boxes have landed
-            prep_brick(ps[0], 0, yc0, wzv0, k0c);
-            prep_brick(ps[1], 0, yc1, wzv1, k1c);
+            prep_brick(ps[0], yc0, wzv0, k0c);
+            prep_brick(ps[1], yc1, wzv1, k1c);
             p1_slice(Rw0, 0, yc0, wzv0, k0c);
             p1_slice(Rw1, 0, yc1, wzv1, k1c);
             lds_barrier();
@@ -302,9 +363,8 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
                 if (gp < G) {
                     if (gp + 1 < G) {
                         if (zi == kBZ - 1) { // the next brick's boxes landed an iteration ago
-                            const int tb1 = (tb == 2) ? 0 : tb + 1;
-                            prep_brick(ps[0], tb1, yc0, wzv0, k0c);
-                            prep_brick(ps[1], tb1, yc1, wzv1, k1c);
+                            prep_brick(ps[0], yc0, wzv0, k0c);
+                            prep_brick(ps[1], yc1, wzv1, k1c);
                         }
                         MBP_STAMP(1);
 #ifdef WN_TUNE_ENV
@@ -421,37 +481,40 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
         const int sw = wave - (kWW + kPW);
         // LDS-DMA of a brick's boxes: one global_load_lds_dwordx4 per (k, j) box row -- lane l moves the 16-byte chunk l of
         // the row (columns 4l..4l+3 from the box's first column rounded down to a multiple of 4, so that no chunk straddles
-        // the tile's wrap-around), the row address is scalar.  The rows of a band are dealt to (store wave, part) pairs,
-        // part = 0..parts-1: one part per plane of the brick's first planes.  Rows past the box's extent of this brick
-        // carry zero weights (wrapped addresses are always valid memory).
+        // the tile's wrap-around), the row address is scalar.  One band per plane over the brick's first planes, a band's rows
+        // dealt to the four store waves.  Rows past the box's extent of this brick carry zero weights (wrapped addresses are
+        // always valid memory).
         // Row offsets first, one lane per box row of a band (a dozen vector instructions per band and brick); a request is
         // then a v_readlane, a 64-bit scalar add, the M0 write and the load.  (Computing each row's address with scalar
         // arithmetic at the request cost ~25 instructions = ~400 cycles of the wave per request.)
-        int rowoff[NB]; // lane r: float offset of the tile row of box row r = (k, j) of band b
-        auto row_offsets = [&](int tbuf) {
+        int bK[NB], bBox[NB], bRow[NB]; // per band: box rows, image offset, image row length (launch constants, in SGPRs)
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int K = sgpr(s_bandc[b][0]);
-                const int jy0 = sgpr(s_mid[tbuf][b][0]) - 1, kz0 = sgpr(s_mid[tbuf][b][kSlotZ]) - 1;
+        for (int b = 0; b < NB; ++b) {
+            bK[b] = sgpr(s_bandc[b][0]);
+            bBox[b] = sgpr(s_bandc[b][1]);
+            bRow[b] = sgpr(s_bandc[b][2]);
+        }
+        // band b's fresh rows for the brick with tables tB (its predecessor: tA): row offsets, then the requests of this wave
+        auto request_band = [&](auto bc, int tA, int tB, bool same_column, bool first) {
+            constexpr int b = decltype(bc)::value;
+            if constexpr (b < NB) {
+                const int K = bK[b];
+                const int d = first ? K : fresh_rows(b, K, tA, tB, same_column);
+                const int jy0 = sgpr(s_mid[tB][b][0]) - 1, kz0 = sgpr(s_mid[tB][b][kSlotZ]) - 1 + (K - d);
                 const int r = min(lane, K * K - 1);
-                const int k = (K == 4) ? (r >> 2) : ((r * 13) >> 6); // r / K for r < 25
-                const int j = r - k * K;
-                rowoff[b] = (((kz0 + k) & a.nmask) * a.n + ((jy0 + j) & a.nmask)) * a.n;
-            }
-        };
-        auto request_boxes = [&](int tbuf, int part, int parts) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int K = sgpr(s_bandc[b][0]), box_off = sgpr(s_bandc[b][1]), rowlen = sgpr(s_bandc[b][2]);
-                const int ix0 = (sgpr(s_mid[tbuf][b][kSlotX]) - 1) & ~3;
+                const int f = (K == 4) ? (r >> 2) : ((r * 13) >> 6); // r / K for r < 25
+                const int j = r - f * K;
+                const int rowoff = (((kz0 + f) & a.nmask) * a.n + ((jy0 + j) & a.nmask)) * a.n; // lane r: tile row of image row r = (f, j)
+                const int ix0 = (sgpr(s_mid[tB][b][kSlotX]) - 1) & ~3;
                 const unsigned voff = (unsigned)((ix0 + 4 * lane) & a.nmask) * 4u;
-                if (4 * lane < rowlen) {
-                    for (int r = sw + kSW * part; r < K * K; r += kSW * parts) {
-                        const char *rowp = reinterpret_cast<const char *>(a.coef + __builtin_amdgcn_readlane(rowoff[b], r));
+                for (int rr = sw; rr < d * K; rr += kSW) {
+                    // the v_readlane with every lane active: inside the lanes' `if` the row offsets of the inactive lanes
+                    // are undefined (and the compiler does sink their computation into it)
+                    const char *rowp = reinterpret_cast<const char *>(a.coef + __builtin_amdgcn_readlane(rowoff, rr));
+                    if (4 * lane < bRow[b])
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rowp + voff),
-                                                         (__attribute__((address_space(3))) void *)&s_box[box_off + r * rowlen],
+                                                         (__attribute__((address_space(3))) void *)&s_box[bBox[b] + rr * bRow[b]],
                                                          16, 0, 0);
-                    }
                 }
             }
         };
@@ -489,8 +552,28 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
             }
         };
 
-        row_offsets(0);
-        request_boxes(0, 0, 1); // the first brick's boxes: all rows at once
+        using std::integral_constant;
+        request_band(integral_constant<int, 0>{}, 0, 0, false, true); // the first brick's boxes: every row of every band
+        request_band(integral_constant<int, 1>{}, 0, 0, false, true);
+        request_band(integral_constant<int, 2>{}, 0, 0, false, true);
+        request_band(integral_constant<int, 3>{}, 0, 0, false, true);
+        request_band(integral_constant<int, 4>{}, 0, 0, false, true);
+        for (int b = sw; b < NB; b += kSW) derive_tables(b, 0, 0, false, true);
+#ifdef WN_TUNE_ENV
+        if (a.debug == 20 && blockIdx.x == 0) { // dump the derived tables of the first brick
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (sw == 0) {
+                float *dump = reinterpret_cast<float *>(g_mbp_stamps);
+                for (int i = lane; i < NB * kMaxK * kBY; i += 64) dump[i] = (&s_wy[0][0][0])[i];
+                for (int i = lane; i < NB * 64; i += 64) dump[256 + i] = (&s_wz[0][0])[i];
+                for (int i = lane; i < NB * 4; i += 64) dump[640 + i] = (float)(&s_prep[0][0])[i];
+                for (int i = lane; i < NB * 4; i += 64) dump[680 + i] = (float)(&s_bandc[0][0])[i];
+            }
+            for (int gp = 0; gp < G + 2; ++gp) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            return;
+        }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
         lds_barrier();
@@ -501,11 +584,21 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
             if (gp < G) {
                 // the next brick's boxes: a part per plane over the first planes of this brick; complete (this wave's share)
                 // before the barrier that ends plane kDmaLanded, which publishes every wave's share to the collapse waves
-                if (zi < kDmaPlanes && t + 1 < nb) {
+                if (zi < NB && t + 1 < nb) { // band zi of the next brick
                     const int tb1 = (tb == 2) ? 0 : tb + 1;
-                    if (zi == 0) row_offsets(tb1);
-                    request_boxes(tb1, zi, kDmaPlanes);
+                    const bool same = nxt.bx == cur.bx && nxt.by == cur.by;
+                    if (zi == 0) request_band(integral_constant<int, 0>{}, tb, tb1, same, false);
+                    else if (zi == 1) request_band(integral_constant<int, 1>{}, tb, tb1, same, false);
+                    else if (zi == 2) request_band(integral_constant<int, 2>{}, tb, tb1, same, false);
+                    else if (zi == 3) request_band(integral_constant<int, 3>{}, tb, tb1, same, false);
+                    else request_band(integral_constant<int, 4>{}, tb, tb1, same, false);
                 }
+                // what the collapse waves need of the next brick at this brick's last plane: one band per store wave (the first
+                // wave also the fifth), in the plane before it.  (Spread over two planes it slowed both: a plane takes as long as
+                // its slowest wave, and the store waves are the slowest in every plane they do anything besides storing.)
+                if (zi == kBZ - 2 && t + 1 < nb)
+                    for (int b = sw; b < NB; b += kSW)
+                        derive_tables(b, tb, (tb == 2) ? 0 : tb + 1, nxt.bx == cur.bx && nxt.by == cur.by, false);
                 // vmcnt counts this wave's memory instructions in issue order: at most 4 x (kDmaLanded - kDmaPlanes + 1)
                 // stores are younger than its last box row, so this wait covers every box row and no more stores than that
                 // (with bricks that stick out of the lattice some stores are skipped and the count does not hold: wait for all)

@@ -39,8 +39,11 @@ def raw_to_json_dict(grid):
 def convert_raw_to_json(raw_file_path, json_file_path, image_size=256):
     """threejs/convert_raw_to_json.py:12-90.  A missing input returns False (:23-25); a float count
     other than image_size^2 re-derives image_size = int(sqrt(count)) (:36-39) and writes that square;
-    a count that is no perfect square cannot be reshaped there (:42, caught at :88-90) -> False."""
+    a count that is no perfect square cannot be reshaped there (:42, caught at :88-90) -> False; a file whose
+    length is no multiple of 4 fails the reference's struct.unpack (:30-33) -> False."""
     if not os.path.exists(raw_file_path):
+        return False
+    if os.path.getsize(raw_file_path) % 4:  # struct.unpack(f'{len//4}f', data) raises on trailing bytes (:30-33) -> :88-90
         return False
     a = np.fromfile(raw_file_path, dtype="<f4")
     if a.size != image_size * image_size:

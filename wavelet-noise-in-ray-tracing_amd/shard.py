@@ -7,6 +7,8 @@ final x-fastest volume, the root receives each peer's slab straight into its pla
 grouped send/recv (RCCL over xGMI on the GPU box: every peer pushes over its own link; gloo in
 the CPU tests).  Nothing is re-packed.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -58,3 +60,60 @@ def gather_volume(slab, nz, dst=0, group=None, out=None, piece_bytes=1 << 30):
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return full
+
+
+class NativeComm:
+    """The C ABI's communicator (include/wnoise_shard.h, libwnoise_shard.so: grouped ncclSend / ncclRecv over RCCL), for
+    callers that do not go through torch.distributed's process group -- and to exercise from Python the entry points
+    tools/gridgen --gpus N uses.  The id travels by torch.distributed when a process group exists (any backend),
+    otherwise `id_bytes` must be handed in (rank 0: NativeComm.unique_id())."""
+
+    def __init__(self, world=None, rank=None, id_bytes=None):
+        from . import _capi_shard as cs
+        self._cs = cs
+        lib = cs.load()
+        if world is None:
+            world = dist.get_world_size() if dist.is_initialized() else 1
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        if id_bytes is None:
+            buf = (C.c_ubyte * cs.WN_COMM_ID_BYTES)()
+            if rank == 0:
+                cs.check(lib.wn_comm_unique_id(buf))
+            if world > 1:
+                t = torch.tensor(list(buf), dtype=torch.uint8)
+                if dist.get_backend() == "nccl":
+                    t = t.cuda()
+                dist.broadcast(t, src=0)
+                buf = (C.c_ubyte * cs.WN_COMM_ID_BYTES)(*t.cpu().tolist())
+            id_bytes = bytes(buf)
+        self.world, self.rank = world, rank
+        self._h = C.c_void_p()
+        idbuf = (C.c_ubyte * cs.WN_COMM_ID_BYTES).from_buffer_copy(id_bytes)
+        cs.check(lib.wn_comm_create(C.byref(self._h), world, rank, idbuf))
+
+    @staticmethod
+    def unique_id():
+        from . import _capi_shard as cs
+        buf = (C.c_ubyte * cs.WN_COMM_ID_BYTES)()
+        cs.check(cs.load().wn_comm_unique_id(buf))
+        return bytes(buf)
+
+    def gather_volume(self, slab, nz, dst=0, out=None, piece_bytes=0):
+        """wn_gather_volume: `slab` [z1-z0, ny, nx] float32 on the current device -> the [nz, ny, nx] volume on `dst`."""
+        ny, nx = slab.shape[-2], slab.shape[-1]
+        slab = slab.contiguous()
+        full = None
+        if self.rank == dst:
+            full = out if out is not None else torch.empty((nz, ny, nx), dtype=torch.float32, device=slab.device)
+        self._cs.check(self._cs.load().wn_gather_volume(
+            self._h, C.c_void_p(slab.data_ptr()), nz, ny, nx, dst, C.c_void_p(full.data_ptr()) if full is not None else None,
+            piece_bytes, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return full
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._cs.load().wn_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

@@ -20,6 +20,7 @@
 //   render [--width W] [--height H] [--spp S] [--noise 0|1] [--octave O] [--band-lines L]
 //          [--out file.ppm] [--rgb file.rgb] [--dry-run]
 //   --dry-run: no GPU; prints the count and FNV-1a64 of the hit-point stream (oracle/_ref check)
+//   --dump-first N file: the first N hit points and their grey values as raw float32 records (x, y, z, grey)
 //   --time-kernel: also times the texture kernel ALONE on every band's hit-point stream (points resident in
 //                  HBM, HIP events, best of 3 launches): the device rate on the renderer's real stream
 #include <cfloat>
@@ -190,6 +191,8 @@ struct Options {
     int width = 1000, height = 500, spp = 100, noise = 1, octave = 4, band_lines = 25;
     std::string out_ppm, out_rgb;
     bool dry_run = false, time_kernel = false;
+    size_t dump_n = 0;      // --dump-first N file: the first N hit points (xyz) and their texture values, raw float32
+    std::string dump_file;
 };
 
 } // namespace
@@ -209,6 +212,7 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--rgb")) opt.out_rgb = next();
         else if (!std::strcmp(argv[i], "--dry-run")) opt.dry_run = true;
         else if (!std::strcmp(argv[i], "--time-kernel")) opt.time_kernel = true;
+        else if (!std::strcmp(argv[i], "--dump-first")) { opt.dump_n = (size_t)std::atoll(next()); opt.dump_file = next(); }
         else { std::fprintf(stderr, "render: unknown option %s\n", argv[i]); return 2; }
     }
     const int width = opt.width, height = opt.height, spp = opt.spp;
@@ -225,7 +229,7 @@ int main(int argc, char **argv)
         std::vector<unsigned char> image((size_t)width * height * 3);
         Fnv stream;
         double t_trace = 0, t_noise = 0, t_kernel = 0;
-        size_t total_points = 0;
+        size_t total_points = 0, dumped = 0;
 
         // per band of scanlines: recorded bounces and per-sample bookkeeping
         std::vector<float> pts;        // xyz of every recorded bounce
@@ -284,6 +288,15 @@ int main(int argc, char **argv)
             else perlin_tex->values(pts.data(), nullptr, npts, grey.data());
             auto t2 = std::chrono::steady_clock::now();
             t_noise += std::chrono::duration<double>(t2 - t1).count();
+            if (opt.dump_n && !opt.dump_file.empty() && dumped < opt.dump_n) { // for the parity test of the full-size stream
+                const size_t take = std::min(opt.dump_n - dumped, npts);
+                std::ofstream f(opt.dump_file, dumped ? std::ios::binary | std::ios::app : std::ios::binary);
+                for (size_t k = 0; k < take; ++k) {
+                    f.write(reinterpret_cast<const char *>(&pts[3 * k]), 3 * sizeof(float));
+                    f.write(reinterpret_cast<const char *>(&grey[k]), sizeof(float));
+                }
+                dumped += take;
+            }
             if (opt.time_kernel && npts) {
                 wnhost::DeviceBuffer in(3 * npts * sizeof(float)), out(npts * sizeof(float));
                 in.upload(pts.data());

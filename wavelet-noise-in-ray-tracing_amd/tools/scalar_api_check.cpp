@@ -60,6 +60,36 @@ int main()
             }
             std::printf("batch_vs_scalar_mismatches %zu\n", bad);
         }
+        // a renderer-sized masked batch through the host classes: 200,000 points, ~59 % active (the reference scene's share
+        // of primary rays that reach a noise-textured surface): the wave-ballot compaction path of the texture kernels as a
+        // C++ caller reaches it; active lanes must equal the unmasked batch, inactive ones keep what was there
+        {
+            const size_t m = 200000;
+            std::vector<float> big(3 * m), full(m), masked(m, -7.0f), fullp(m), maskedp(m, -7.0f);
+            std::vector<uint8_t> active(m);
+            uint32_t st = 12345u;
+            auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (st >> 8) * (1.0f / 16777216.0f); };
+            size_t on = 0;
+            for (size_t i = 0; i < m; ++i) {
+                big[3 * i] = rnd() * 20.0f - 10.0f;
+                big[3 * i + 1] = (i % 7 == 0) ? rnd() - 0.5f : -0.5f;
+                big[3 * i + 2] = rnd() * 20.0f - 10.0f;
+                active[i] = rnd() < 0.593f;
+                on += active[i];
+            }
+            auto *wtex = dynamic_cast<wavelet_texture *>(wt.get());
+            auto *ptex = dynamic_cast<noise_texture *>(pt.get());
+            wtex->values(big.data(), nullptr, m, full.data());
+            wtex->values(big.data(), active.data(), m, masked.data());
+            ptex->values(big.data(), nullptr, m, fullp.data());
+            ptex->values(big.data(), active.data(), m, maskedp.data());
+            size_t bad = 0;
+            for (size_t i = 0; i < m; ++i) {
+                bad += masked[i] != (active[i] ? full[i] : -7.0f);
+                bad += maskedp[i] != (active[i] ? fullp[i] : -7.0f);
+            }
+            std::printf("masked_batch_mismatches %zu active %zu of %zu\n", bad, on, m);
+        }
         // conventions: an un-generated object evaluates to 0 (WaveletNoise.cpp:112,186,219)
         std::printf("empty %.9g %.9g\n", empty.evaluate3D(&pts[0]), empty.evaluate2D(&pts[0]));
         std::printf("tile %d coeffs %zu\n", n3.getTileSize(), n3.getNoiseCoefficients().size());
