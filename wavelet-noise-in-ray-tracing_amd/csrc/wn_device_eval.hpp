@@ -76,35 +76,6 @@ __device__ __forceinline__ float eval3d_exact(const float *coef, int n, int nmas
     return result;
 }
 
-// evaluate3D with the coefficient rows coming from `rows`: rows(yi, zi) -> the padded row (n + 2 floats, the two
-// wrap-around columns last) of tile row yi in plane zi, both already reduced modulo n.  Same mids, weights, products
-// and accumulation order as eval3d_exact (WaveletNoise.cpp:185-215): only where a coefficient is read from changes
-// (an LDS patch staged by the workgroup, wn_wavelet_points.hip), so the value keeps the reference's bits.
-template <typename Rows>
-__device__ __forceinline__ float eval3d_exact_rows(const Rows &rows, int n, int nmask, float px, float py, float pz)
-{
-    int mx, my, mz;
-    float wx[3], wy[3], wz[3];
-    bspline(px, mx, wx[0], wx[1], wx[2]);
-    bspline(py, my, wy[0], wy[1], wy[2]);
-    bspline(pz, mz, wz[0], wz[1], wz[2]);
-    const int cx0 = dmod(mx - 1, n, nmask);
-    float result = 0.0f;
-#pragma unroll
-    for (int fz = 0; fz < 3; ++fz)
-#pragma unroll
-        for (int fy = 0; fy < 3; ++fy) {
-            float c[3];
-            __builtin_memcpy(c, rows(dmod(my + fy - 1, n, nmask), dmod(mz + fz - 1, n, nmask)) + cx0, sizeof(c));
-#pragma unroll
-            for (int fx = 0; fx < 3; ++fx) {
-                const float weight = wx[fx] * wy[fy] * wz[fz];
-                result += weight * c[fx];
-            }
-        }
-    return result;
-}
-
 // WaveletNoise::evaluate3DProjected, WaveletNoise.cpp:218-265: data-dependent support box,
 // `break` on the first axis outside the basis support, contributions <= 1e-6 skipped.
 __device__ __forceinline__ float projected_exact(const float *coef, int n, int nmask,

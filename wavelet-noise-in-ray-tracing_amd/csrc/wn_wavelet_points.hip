@@ -290,142 +290,6 @@ __global__ __launch_bounds__(256) void plane_sorted_points_kernel(const Ops ops)
         if (ops.active(begin + i)) ops.store(begin + i, value[i]);
 }
 
-// ---- patch kernel (round 3) ---------------------------------------------------------------------------------------------
-// The TA counters of the kernel above (profiles/r03a_texture_points_ta_counters.json) say what binds it: the texture
-// addressers are busy 0.82-0.92 of the time and address-stalled by the L1 0.45 of it -- nine divergent 12-byte gathers per
-// point, one cache line per lane and clock -- and the 8.6 MB padded tile does not fit an XCD's 4 MiB L2, so those lines come
-// over the fabric 3.4 times the algorithmic bytes.  Ray hits lie on surfaces: sorted by the coefficient plane of one axis,
-// 256 neighbours of the sorted order touch a PATCH of a few planes x a few rows of the tile (the reference scene's ground
-// quad: 8-10 planes x 3 rows).  The workgroup stages that patch in LDS -- whole 520-byte padded rows, coalesced 8-byte
-// loads: ~60 bytes of L2 traffic per point instead of ~600 -- and every lane runs the SAME 27-tap loop on it
-// (eval3d_exact_rows: same mids, weights, products, order): the values keep the reference's bits, the gathers become LDS
-// reads.  A batch whose patch would not fit (points scattered in all three dimensions) takes the gathers as before.
-// Which axis is sorted is decided per chunk: the one over which the chunk spreads more (z for a floor, y for a wall in z).
-constexpr int kPatchRows = 40;                    // padded rows of a patch (n = 128: 20.8 KB)
-constexpr int kPatchBatch = 256;                  // points evaluated from one patch: one per thread
-
-struct PatchRows {
-    const float *base;
-    int zlo, ylo, nyr, stride, nmask;
-    __device__ const float *operator()(int yi, int zi) const
-    {
-        return base + (((zi - zlo) & nmask) * nyr + ((yi - ylo) & nmask)) * stride;
-    }
-};
-
-template <typename Ops>
-__global__ __launch_bounds__(256) void patch_points_kernel(const Ops ops, int patch_floats)
-{
-    extern __shared__ __attribute__((aligned(16))) float patch[]; // kPatchRows x (n + 2)
-    __shared__ unsigned hist[128];
-    __shared__ unsigned wave_total[4];
-    __shared__ int s_range[8]; // chunk: zmin zmax ymin ymax; batch: the same at +4
-    __shared__ unsigned short order[kSortChunk];
-    __shared__ unsigned short mids[kSortChunk]; // (mz & 127) | (my & 127) << 8; 0xffff: inactive
-    __shared__ float value[kSortChunk];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t begin = (size_t)blockIdx.x * kSortChunk;
-    const int count = (int)min((size_t)kSortChunk, ops.count - begin);
-    const int n = ops.tile_n(), nmask = n - 1, stride = n + 2;
-    if (tid < 128) hist[tid] = 0;
-    if (tid < 8) s_range[tid] = (tid & 1) ? -1 : 1 << 20;
-    __syncthreads();
-    auto wave_minmax = [&](int lo, int hi, int *dst) { // wave reduction, then one LDS atomic pair per wave
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            lo = min(lo, __shfl_xor(lo, d, 64));
-            hi = max(hi, __shfl_xor(hi, d, 64));
-        }
-        if (lane == 0) {
-            atomicMin(dst, lo);
-            atomicMax(dst + 1, hi);
-        }
-    };
-    // pass 1: the points' coefficient planes and rows (binned), and how far the chunk spreads over each axis
-    {
-        int zlo = 1 << 20, zhi = -1, ylo = 1 << 20, yhi = -1;
-#pragma unroll
-        for (int k = 0; k < kSortPerThread; ++k) {
-            const int i = tid + 256 * k;
-            unsigned short m = 0xffff;
-            if (i < count && ops.active(begin + i)) {
-                const int z = ops.mid_z(begin + i) & nmask & 127, y = ops.mid_y(begin + i) & nmask & 127;
-                m = (unsigned short)(z | (y << 8));
-                zlo = min(zlo, z); zhi = max(zhi, z); ylo = min(ylo, y); yhi = max(yhi, y);
-            }
-            if (i < kSortChunk) mids[i] = m;
-        }
-        wave_minmax(zlo, zhi, &s_range[0]);
-        wave_minmax(ylo, yhi, &s_range[2]);
-    }
-    __syncthreads();
-    const bool by_y = (s_range[3] - s_range[2]) > (s_range[1] - s_range[0]); // sort the axis the chunk spreads over more
-    // pass 2: counting sort by that axis' plane (one LDS atomic per point)
-    unsigned short rank[kSortPerThread];
-#pragma unroll
-    for (int k = 0; k < kSortPerThread; ++k) {
-        const unsigned short m = mids[tid + 256 * k];
-        rank[k] = 0;
-        if (m != 0xffff) rank[k] = (unsigned short)atomicAdd(&hist[by_y ? (m >> 8) : (m & 127)], 1u);
-    }
-    __syncthreads();
-    if (tid < 64) { // exclusive prefix sum of the 128 bins: two per lane of the first wave
-        const unsigned a0 = hist[2 * lane], a1 = hist[2 * lane + 1];
-        unsigned inc = a0 + a1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned t = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += t;
-        }
-        hist[2 * lane] = inc - a0 - a1;
-        hist[2 * lane + 1] = inc - a1;
-        if (lane == 63) wave_total[0] = inc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kSortPerThread; ++k) {
-        const unsigned short m = mids[tid + 256 * k];
-        if (m != 0xffff) order[hist[by_y ? (m >> 8) : (m & 127)] + rank[k]] = (unsigned short)(tid + 256 * k);
-    }
-    __syncthreads();
-    // pass 3: batches of 256 points in sorted order, each from its patch when the patch fits
-    const int n_active = (int)wave_total[0];
-    for (int s0 = 0; s0 < n_active; s0 += kPatchBatch) {
-        const int sidx = s0 + tid;
-        const bool mine = sidx < n_active;
-        const int i = mine ? order[sidx] : 0;
-        {
-            const unsigned short m = mine ? mids[i] : 0;
-            const int z = m & 127, y = m >> 8;
-            wave_minmax(mine ? z : 1 << 20, mine ? z : -1, &s_range[4]);
-            wave_minmax(mine ? y : 1 << 20, mine ? y : -1, &s_range[6]);
-        }
-        __syncthreads();
-        const int zlo = s_range[4] - 1, nzr = s_range[5] - s_range[4] + 3;
-        const int ylo = s_range[6] - 1, nyr = s_range[7] - s_range[6] + 3;
-        const int rows = nzr * nyr;
-        const bool fits = rows * stride <= patch_floats;
-        if (fits) { // whole padded rows of the tile, 8 bytes per lane, coalesced
-            const int per_row = stride / 2; // n + 2 is even
-            for (int e = tid; e < rows * per_row; e += 256) {
-                const int r = e / per_row, c2 = e - r * per_row;
-                const int zr = r / nyr, yr = r - zr * nyr;
-                const float *src = ops.padded_tile() + (size_t)((((zlo + zr) & nmask) * n) + ((ylo + yr) & nmask)) * stride + 2 * c2;
-                *reinterpret_cast<float2 *>(patch + r * stride + 2 * c2) = *reinterpret_cast<const float2 *>(src);
-            }
-        }
-        __syncthreads();
-        if (mine) {
-            if (fits) value[i] = ops.eval_rows(begin + i, PatchRows{patch, zlo & nmask, ylo & nmask, nyr, stride, nmask});
-            else value[i] = ops.eval(begin + i);
-        }
-        if (tid < 4) s_range[4 + tid] = (tid & 1) ? -1 : 1 << 20;
-        __syncthreads();
-    }
-    for (int i = tid; i < count; i += 256)
-        if (mids[i] != 0xffff) ops.store(begin + i, value[i]);
-}
-
 __device__ __forceinline__ int mid_of(float p) { return (int)ceilf(p - 0.5f); } // WaveletNoise.cpp:194-196
 
 // wavelet_texture::value (texture.h:67-107) on a 3-D tile
@@ -441,21 +305,11 @@ struct TextureOps {
         return mid_of(p);
     }
     __device__ int mid_z(size_t i) const { return mid(a.pts[3 * i + 2]); }
-    __device__ int mid_y(size_t i) const { return mid(a.pts[3 * i + 1]); }
     __device__ int mid_x(size_t i) const { return mid(a.pts[3 * i]); }
     __device__ float eval(size_t i) const
     {
         const float *p = a.pts + 3 * i;
         return wavelet_texture_value<PADDED>(a, p[0], p[1], p[2]);
-    }
-    static constexpr bool kPatch = PADDED; // rows can be staged in LDS from the padded tile copy
-    __device__ const float *padded_tile() const { return a.coef; }
-    __device__ int tile_n() const { return a.n; }
-    template <typename Rows>
-    __device__ float eval_rows(size_t i, const Rows &rows) const
-    {
-        const float *p = a.pts + 3 * i;
-        return wn::wavelet_texture_value_rows(a, rows, p[0], p[1], p[2]);
     }
     __device__ void store(size_t i, float v) const { a.grey[i] = v; }
 };
@@ -469,16 +323,6 @@ struct Eval3dOps {
     __device__ float key_scale() const { return a.band_scale[a.nbands - 1]; }
     __device__ int mid_z(size_t i) const { return MULTIBAND ? mid_of(2.0f * a.pts[3 * i + 2] * key_scale()) : mid_of(a.pts[3 * i + 2]); }
     __device__ int mid_x(size_t i) const { return MULTIBAND ? mid_of(2.0f * a.pts[3 * i] * key_scale()) : mid_of(a.pts[3 * i]); }
-    __device__ int mid_y(size_t i) const { return MULTIBAND ? mid_of(2.0f * a.pts[3 * i + 1] * key_scale()) : mid_of(a.pts[3 * i + 1]); }
-    static constexpr bool kPatch = PADDED && !MULTIBAND; // (several bands have several boxes: they keep the gathers)
-    __device__ const float *padded_tile() const { return a.coef; }
-    __device__ int tile_n() const { return a.n; }
-    template <typename Rows>
-    __device__ float eval_rows(size_t i, const Rows &rows) const
-    {
-        const float *p = a.pts + 3 * i;
-        return wn::eval3d_exact_rows(rows, a.n, a.nmask, p[0], p[1], p[2]);
-    }
     __device__ float eval(size_t i) const
     {
         const float *p = a.pts + 3 * i;
@@ -494,29 +338,11 @@ struct Eval3dOps {
     __device__ void store(size_t i, float v) const { a.out[i] = v; }
 };
 
-inline bool patch_enabled()
-{
-#ifdef WN_TUNE_ENV
-    if (getenv("WN_NO_POINT_PATCH")) return false;
-#endif
-    return true;
-}
-
 template <typename Ops>
 int launch_sorted(const Ops &ops, hipStream_t stream)
 {
     const size_t blocks = (ops.count + kSortChunk - 1) / kSortChunk;
     if (blocks > 0x7fffffffull) return WN_ERR_INVALID;
-    if constexpr (Ops::kPatch) {
-        const int n = ops.a.n;
-        // power-of-two tiles of at most 128 rows per axis bin one-to-one into the 128 sort bins and 7-bit mids
-        if (patch_enabled() && n >= 4 && n <= 128 && (n & (n - 1)) == 0) {
-            const int patch_floats = kPatchRows * (n + 2);
-            hipLaunchKernelGGL((patch_points_kernel<Ops>), dim3((unsigned)blocks), dim3(256), patch_floats * sizeof(float), stream,
-                               ops, patch_floats);
-            return WN_OK;
-        }
-    }
     hipLaunchKernelGGL((plane_sorted_points_kernel<Ops>), dim3((unsigned)blocks), dim3(256), 0, stream, ops);
     return WN_OK;
 }
