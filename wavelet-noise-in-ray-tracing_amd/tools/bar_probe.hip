@@ -21,7 +21,7 @@ __global__ void pingpong(volatile uint32_t *req, volatile uint32_t *resp, int ro
         long long spins = 0;
         do {
             v = __hip_atomic_load((uint32_t *)req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (++spins > 400000000ll) return; // never hang
+            if (++spins > 20000000ll) return; // never hang
         } while (v == last);
         last = v;
         __hip_atomic_store((uint32_t *)resp, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -55,7 +55,7 @@ static double run(volatile uint32_t *req_host, uint32_t *req_dev, volatile uint3
         __atomic_store_n((uint32_t *)req_host, r, __ATOMIC_RELEASE);
         long long spins = 0;
         while (__atomic_load_n((uint32_t *)resp_host, __ATOMIC_ACQUIRE) != r)
-            if (++spins > 2000000000ll) { std::printf("  host gave up at round %u\n", r); return -1; }
+            if (++spins > 200000000ll) { std::printf("  host gave up at round %u\n", r); (void)hipDeviceSynchronize(); return -1; }
     }
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / rounds;
     (void)hipDeviceSynchronize();
@@ -64,7 +64,8 @@ static double run(volatile uint32_t *req_host, uint32_t *req_dev, volatile uint3
 
 int main()
 {
-    const int rounds = 200000;
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const int rounds = 20000;
     uint32_t *pinned = nullptr, *pinned_dev = nullptr;
     if (hipHostMalloc((void **)&pinned, 4096, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return 1;
     (void)hipHostGetDevicePointer((void **)&pinned_dev, pinned, 0);
@@ -79,6 +80,10 @@ int main()
         if (e != hipSuccess) { std::printf("%s: allocation failed (%s)\n", t.name, hipGetErrorString(e)); (void)hipGetLastError(); continue; }
         (void)hipMemset(dev, 0, 4096);
         (void)hipDeviceSynchronize();
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, dev) == hipSuccess)
+            std::printf("%s: type %d, hostPointer %p, devicePointer %p, isManaged %d\n", t.name, (int)at.type, at.hostPointer, at.devicePointer, (int)at.isManaged);
+        std::printf("%s: touching it from the host ...\n", t.name);
         const bool ok = host_can_touch(dev);
         std::printf("%s: host %s touch it\n", t.name, ok ? "CAN" : "cannot");
         if (ok)
