@@ -96,10 +96,11 @@ int check_handle_device(int handle_device, const char *what);
 // wn_wavelet_strip.hip: launches the strip-march kernel when the lattice is in its regime.
 int strip_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_t stream, bool *launched);
 
-// wn_wavelet_multiband.hip: launches the plane-pipeline kernel when a multiband lattice is in its regime (g carries the
-// bands' common post_scale; oscale / weights per band; out_div = sqrt(sum w^2 * variance)).
+// wn_wavelet_multiband.hip: launches the plane-pipeline kernel when a lattice of 1..5 bands is in its regime (g carries the
+// bands' common post_scale; oscale / weights per band; out_div = sqrt(sum w^2 * variance)) and has at least
+// min_bricks_per_cu bricks of 512 x 8 x 8 samples per compute unit.
 int multiband_try(const wn_tile *tile, const GridArgs &g, int nbands, const float *oscale, const float *weights,
-                  float out_div, float *out_dev, hipStream_t stream, bool *launched);
+                  float out_div, float *out_dev, hipStream_t stream, bool *launched, int min_bricks_per_cu);
 
 // wn_wavelet_exact.hip: bit-exact dense 3-D grids with the coefficient box staged in LDS; *launched tells the caller.
 int exact_lds_try(const wn_tile *tile, const GridArgs &g, float *out_dev, hipStream_t stream, bool *launched);

@@ -639,16 +639,17 @@ extern "C" __attribute__((visibility("default"))) int wn_debug_mbp_stamps(long l
 namespace wn {
 
 // Plans and launches the plane-pipeline kernel when the lattice is in its regime (else *launched = false and the
-// caller goes on to the brick kernel): 2..5 consecutive-octave bands, rows wider than 256 samples and a multiple of 4,
+// caller goes on to the strip / brick kernels): 1..5 consecutive-octave bands, rows wider than 256 samples and a multiple of 4,
 // power-of-two tile, every band's (y, z) box of 8 samples at most 5 rows, at most 8 passes of 64 box columns.
 int multiband_try(const wn_tile *tile, const GridArgs &g, int nbands, const float *oscale, const float *weights,
-                  float out_div, float *out_dev, hipStream_t stream, bool *launched)
+                  float out_div, float *out_dev, hipStream_t stream, bool *launched, int min_bricks_per_cu)
 {
     *launched = false;
 #ifdef WN_TUNE_ENV
     if (getenv("WN_NO_MBP")) return WN_OK;
+    if (nbands == 1 && getenv("WN_NO_MBP1")) return WN_OK;
 #endif
-    if (nbands < 2 || nbands > kMaxNB || tile->n == 0 || pow2_mask(tile->n) < 0) return WN_OK;
+    if (nbands < 1 || nbands > kMaxNB || tile->n == 0 || pow2_mask(tile->n) < 0) return WN_OK;
     if (g.nx <= 256 || (g.nx & 3) || g.ny <= 0 || g.nz <= 0 || g.z_const_mode || g.z0 < 0) return WN_OK;
     if (reinterpret_cast<uintptr_t>(out_dev) & 15) return WN_OK;
     MbArgs a{};
@@ -695,8 +696,14 @@ int multiband_try(const wn_tile *tile, const GridArgs &g, int nbands, const floa
     a.all_full = (g.nx % kBX == 0 && g.ny % kBY == 0 && g.nz % kBZ == 0) ? 1 : 0;
     const long long bricks = (long long)a.nbx * a.nby * a.nbz;
     if (bricks > 0x7fffffffLL / kBZ) return WN_OK;
+    // Single-band callers ask for a minimum of bricks per workgroup (the pipeline's fill and drain are per workgroup: with
+    // two bricks each the strip kernel is faster, 17.2 against 18.0 us on a 512 x 512 x 64 slab) and every caller keeps away
+    // lattices whose last 512-wide brick column is mostly padding (768 = 512 + 256: 394 us here, 314 us on 256-wide bricks).
+    if (bricks < (long long)min_bricks_per_cu * wn::device_compute_units(wn::current_device())) return WN_OK;
+    if ((long long)a.nbx * kBX * 10 > (long long)g.nx * 11) return WN_OK;
     bool ok;
     switch (nbands) {
+    case 1: ok = launch_mbp<1>(a, lds, bricks, stream); break;
     case 2: ok = launch_mbp<2>(a, lds, bricks, stream); break;
     case 3: ok = launch_mbp<3>(a, lds, bricks, stream); break;
     case 4: ok = launch_mbp<4>(a, lds, bricks, stream); break;
