@@ -21,7 +21,8 @@ run() { # <log> <cmd...>
   [ $rc -eq 0 ] || echo "failed rc=$rc: $log"
 }
 
-# (a TA_* counter pass hung rocprofv3 on this pool -- 240 s without output -- and is left out)
+# (four TA_* counters in one pass exceed the TA block's slots: rocprofv3 refuses them with error 38 and aborts; they are taken one per
+# pass by profiles/collect_ta.sh)
 PASSES=(
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"
   "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS"
