@@ -306,14 +306,11 @@ class Workload:
                 self.step = wn.wavelet_volume_launcher(noise, n, n, n, z0, z1, OCTAVE, self.out, exact=exact)
                 # the library's dispatch (csrc/wn_wavelet_strip.hip strip_try): rows of k*256 samples and
                 # 0.18 <= planes per lattice step <= 1/3 go to the strip-march kernel, other lattices to the brick kernel
-                # and before both (csrc/wn_wavelet_grid.hip wn_eval3d_grid -> wn_wavelet_multiband.hip multiband_try): lattices of
-                # >= 4 bricks of 512 x 8 x 8 samples per CU whose rows fill 512-wide bricks go to the single-band plane pipeline
+                # and before both (csrc/wn_wavelet_grid.hip wn_eval3d_grid -> wn_wavelet_multiband.hip multiband_try): lattices
+                # whose rows fill 512-wide bricks and whose step is below 2/7 of a cell go to the single-band plane pipeline
                 lattice_step = 4.0 * 2.0 ** OCTAVE * 2.0 / n
                 strip = n % 256 == 0 and 0.18 <= lattice_step < 1.0 / 3.0
-                bricks = -(-n // 512) * -(-n // 8) * -(-planes // 8)
-                cus = wn.device_info()["compute_units"]
-                pipeline = (n > 256 and n % 4 == 0 and lattice_step < 2.0 / 7.0 and -(-n // 512) * 512 * 10 <= n * 11
-                            and bricks >= (4 if strip else 2) * cus)
+                pipeline = n > 256 and n % 4 == 0 and lattice_step < 2.0 / 7.0 and -(-n // 512) * 512 * 10 <= n * 11
                 self.kernel = ("grid3d_exact_lds_kernel" if exact else "grid3d_mbp_kernel<1" if pipeline else
                                "grid3d_strip_kernel" if strip else "grid3d_sep_kernel<1")
                 which = ("configs[1]" if (world == 1 and n == 512 and planes == 512) else

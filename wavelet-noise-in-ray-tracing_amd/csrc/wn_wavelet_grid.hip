@@ -791,16 +791,17 @@ int wn_eval3d_grid(const wn_tile *tile, const wn_grid *grid, float *out_dev, voi
     if (!(grid->flags & WN_GRID_EXACT)) {
         bool launched = false;
         // The plane pipeline of wn_wavelet_multiband.hip with a single band (16-wave workgroups split into window / collapse /
-        // store waves; the waves that store never compute or wait for a load) where a workgroup gets enough bricks to amortise
-        // its fill and drain: 512^3 91-93 us sustained against 101.9 for the strip kernel, 1024^3 664 against 809 us and the
-        // 2048 x 2048 x 256 shard 646 against 710 us for the brick kernel (round 3, profiles/r03_single_band_plane_pipeline.txt).
-        // Thin slabs go to the strip kernel, lattices the pipeline does not cover to the brick kernel.
+        // store waves; the waves that store never compute or wait for a load): 512^3 91-93 us sustained against 101.9 for the
+        // strip kernel, 1024^3 664 against 809 us and the 2048 x 2048 x 256 shard 646 against 710 us for the brick kernel
+        // (round 3, profiles/r03_single_band_plane_pipeline.txt).  It takes EVERY lattice in its regime, thin slabs included
+        // (512 x 512 x 64: 18.0 us against 17.2 for the strip kernel): a sample's bits must not depend on how the volume was cut
+        // into z-slabs, so the choice of kernel must not depend on the slab's thickness (the kernels differ in the last bits:
+        // each sums in its own order).  The strip and brick kernels serve what the pipeline does not cover (rows of 256 or 768
+        // samples, steps above 2/7 of a cell).
         const float os1 = g.octave_scale, w1 = 1.0f;
-        rc = multiband_try(tile, g, 1, &os1, &w1, 1.0f, out_dev, as_stream(stream), &launched, 4);
+        rc = multiband_try(tile, g, 1, &os1, &w1, 1.0f, out_dev, as_stream(stream), &launched, 0);
         if (rc || launched) return rc;
         rc = strip_try(tile, g, out_dev, as_stream(stream), &launched); // rows of k*256 samples, >= 0.18 planes per step
-        if (rc || launched) return rc;
-        rc = multiband_try(tile, g, 1, &os1, &w1, 1.0f, out_dev, as_stream(stream), &launched, 2);
         if (rc || launched) return rc;
         SepArgs a{};
         size_t lds = 0;

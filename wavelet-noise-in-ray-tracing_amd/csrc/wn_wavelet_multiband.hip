@@ -696,9 +696,9 @@ int multiband_try(const wn_tile *tile, const GridArgs &g, int nbands, const floa
     a.all_full = (g.nx % kBX == 0 && g.ny % kBY == 0 && g.nz % kBZ == 0) ? 1 : 0;
     const long long bricks = (long long)a.nbx * a.nby * a.nbz;
     if (bricks > 0x7fffffffLL / kBZ) return WN_OK;
-    // Single-band callers ask for a minimum of bricks per workgroup (the pipeline's fill and drain are per workgroup: with
-    // two bricks each the strip kernel is faster, 17.2 against 18.0 us on a 512 x 512 x 64 slab) and every caller keeps away
-    // lattices whose last 512-wide brick column is mostly padding (768 = 512 + 256: 394 us here, 314 us on 256-wide bricks).
+    // (min_bricks_per_cu: a caller may keep small lattices away; the product passes 0 -- the kernel of a sample must not depend
+    // on the thickness of the slab it is computed in.)  Every caller keeps away lattices whose last 512-wide brick column is
+    // mostly padding (768 = 512 + 256: 394 us here, 314 us on 256-wide bricks).
     if (bricks < (long long)min_bricks_per_cu * wn::device_compute_units(wn::current_device())) return WN_OK;
     if ((long long)a.nbx * kBX * 10 > (long long)g.nx * 11) return WN_OK;
     bool ok;
