@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libwnoise_hip.so")
+# WN_HIP_LIBRARY: another build of the SAME library (the -DWN_TUNE_ENV development build, `make tune`); still no fallback
+LIB_PATH = os.environ.get("WN_HIP_LIBRARY") or os.path.join(HERE, "libwnoise_hip.so")
 
 WN_OK, WN_ERR_INVALID, WN_ERR_NO_DEVICE, WN_ERR_HIP, WN_ERR_ALLOC = range(5)
 WN_Z_LATTICE, WN_Z_CONST = 0, 1

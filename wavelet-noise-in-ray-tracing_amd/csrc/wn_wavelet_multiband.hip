@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
     __shared__ float s_oscale[NB];
     // derived per brick and band by the store waves an iteration before the collapse waves need them:
     __shared__ __attribute__((aligned(16))) float s_wy[NB][kMaxK][kBY]; // zero-padded y weights x the band's factor: [box row j][row of samples]
-    __shared__ float s_wz[NB][64];                                      // zero-padded z weights dealt to register slots: [plane*8 + slot]
+    __shared__ float s_wz[NB][64];                                      // per plane: three z weights in tap order + the first tap's register slot: [plane*8 + j]
     __shared__ int s_prep[NB][4];                                       // {slot of the box's first row, fresh rows, first column & 3, -}
     __shared__ int s_bandc[NB][4]; // {K, box_off, rowlen, first_pass}: read with ds_read, not reloaded from the kernel arguments
 
@@ -189,9 +189,9 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
 
     // One wave per band b (a store wave: few live registers, time to spare), for the brick with tables tB that follows the
     // brick with tables tA:
-    //  * s_wz[b][plane*8 + slot]: the K box rows in z live in K register slots of the collapse waves as a ring -- tile row
-    //    kabs sits in slot kabs mod K, so the rows a brick keeps from its predecessor stay where they are and the z weights
-    //    are dealt to the slots instead;  * s_wy[b][j][yi]: zero-padded y weights with the band's factor folded in;
+    //  * s_wz[b][plane*8 + {0,1,2 | 3}]: the K box rows in z live in K register slots of the collapse waves as a ring -- tile
+    //    row kabs sits in slot kabs mod K, so the rows a brick keeps from its predecessor stay where they are; a plane gets its
+    //    three z weights (tap order) and the slot of its first tap;  * s_wy[b][j][yi]: zero-padded y weights with the band's factor folded in;
     //  * s_prep[b]: the slot of the box's first row, how many of its top rows are fresh, its first column modulo 4.
     auto derive_tables = [&](int b, int tA, int tB, bool same_column, bool first) {
         const int l = lane;
@@ -200,14 +200,12 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
             const int kz0 = s_mid[tB][b][kSlotZ] - 1;
             // K is 4 or 5: the two modulos by cases (a division by a run-time K is ~30 instructions)
             const int kzm = (K == 4) ? (kz0 & 3) : ((kz0 + 20 * 65536) % 5); // slot of the box's first row
-            {
-                const int zi = l >> 3, slot = l & 7;
-                int tau = slot - kzm + K; // box row (0 = first) held by `slot`: (slot - kzm) mod K, operand in [1, 2K+2]
-                if (K == 4) tau &= 3;
-                else tau -= (tau >= 10) ? 10 : (tau >= 5 ? 5 : 0);
-                const int dd = tau - (s_mid[tB][b][kSlotZ + zi] - s_mid[tB][b][kSlotZ]);
+            { // lane (zi, j): j < 3 the plane's three z weights in tap order, j == 3 the register slot of its first tap
+                const int zi = l >> 3, j = l & 7;
+                int t0 = kzm + (s_mid[tB][b][kSlotZ + zi] - s_mid[tB][b][kSlotZ]); // < 2K
+                t0 -= (t0 >= K) ? K : 0;
                 const float w0 = s_w[tB][b][kSlotZ + zi][0], w1 = s_w[tB][b][kSlotZ + zi][1], w2 = s_w[tB][b][kSlotZ + zi][2];
-                s_wz[b][l] = (slot < K && (unsigned)dd <= 2u) ? (dd == 0 ? w0 : dd == 1 ? w1 : w2) : 0.0f;
+                s_wz[b][l] = j == 0 ? w0 : j == 1 ? w1 : j == 2 ? w2 : __int_as_float(t0);
             }
             if (l < kMaxK * kBY) {
                 const int j = l >> 3, yi = l & 7;
@@ -297,7 +295,7 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
         // plane by the time stamps.)  Marching along z, brick t+1's box is brick t's moved up by d rows: the rows it keeps
         // stay in their registers, only the d fresh rows are collapsed (whole boxes cost ~4,400 cycles of the brick's last
         // plane and 89 DMA requests a brick; at 512^3 x 5 bands d = 2 of 5 rows for the top band, <= 1 of 4 below).
-        // wzv: lane (zi*8 + tap) = zero-padded z weight of plane zi at box row tap.
+        // wzv: lanes zi*8 + 0..2 = the z weights of plane zi in tap order, lane zi*8 + 3 = the slot of its first tap.
         auto prep_brick = [&](const Pass &P, auto &yc, float &wzv, auto kc) {
             constexpr int K = decltype(kc)::value;
             if constexpr (K > 0) {
@@ -331,17 +329,27 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
         auto p1_slice = [&](float *Rw, int zi, const auto &yc, float wzv, auto kc) {
             constexpr int K = decltype(kc)::value;
             if constexpr (K > 0) {
-                float wz[K];
+                // the three taps in the order of the rows (first tap first), whichever slots hold them: the sum's bits depend
+                // on the tile rows and the weights only -- not on where the march began, and they repeat with the tile's period
+                const float w0 = readlane_f(wzv, zi * 8), w1 = readlane_f(wzv, zi * 8 + 1), w2 = readlane_f(wzv, zi * 8 + 2);
+                const int t0 = __builtin_amdgcn_readlane(__float_as_int(wzv), zi * 8 + 3);
+                auto taps = [&](auto tc) {
+                    constexpr int T0 = decltype(tc)::value, T1 = (T0 + 1) % K, T2 = (T0 + 2) % K;
 #pragma unroll
-                for (int k = 0; k < K; ++k) wz[k] = readlane_f(wzv, zi * 8 + k);
-#pragma unroll
-                for (int p2 = 0; p2 < kBY / 2; ++p2) { // rows of samples in pairs: v_pk_fma_f32, the weight a scalar splat
-                    v2f v = v2f{wz[0], wz[0]} * yc[p2][0];
-#pragma unroll
-                    for (int k = 1; k < K; ++k) v = __builtin_elementwise_fma(v2f{wz[k], wz[k]}, yc[p2][k], v);
-                    Rw[(2 * p2) * kRRow] = v.x;
-                    Rw[(2 * p2 + 1) * kRRow] = v.y;
-                }
+                    for (int p2 = 0; p2 < kBY / 2; ++p2) { // rows of samples in pairs: v_pk_fma_f32, the weight a scalar splat
+                        v2f v = v2f{w0, w0} * yc[p2][T0];
+                        v = __builtin_elementwise_fma(v2f{w1, w1}, yc[p2][T1], v);
+                        v = __builtin_elementwise_fma(v2f{w2, w2}, yc[p2][T2], v);
+                        Rw[(2 * p2) * kRRow] = v.x;
+                        Rw[(2 * p2 + 1) * kRRow] = v.y;
+                    }
+                };
+                using std::integral_constant;
+                if (t0 == 0) taps(integral_constant<int, 0>{});
+                else if (t0 == 1) taps(integral_constant<int, 1>{});
+                else if (t0 == 2) taps(integral_constant<int, 2>{});
+                else if (t0 == 3 || K == 4) taps(integral_constant<int, 3>{});
+                else taps(integral_constant<int, K - 1>{});
             }
         };
         // Both passes' K fixed at compile time (K = 0: no such pass): register arrays of exactly 8 x K values per pass and

@@ -557,7 +557,10 @@ int wn_wavelet_texture_points(const wn_tile *tile, int use_3d, double scale, int
     const size_t waves = (n + a.points_per_wave - 1) / a.points_per_wave;
     const size_t blocks = (waves + 3) / 4;
     if (blocks > 0x7fffffffull) return fail(WN_ERR_INVALID, "too many points");
-    const bool padded = has_tile && use_3d && tile->dev_padded;
+    bool padded = has_tile && use_3d && tile->dev_padded;
+#ifdef WN_TUNE_ENV
+    if (getenv("WN_POINTS_UNPADDED")) padded = false; // 27 dword gathers per point instead of 9 dwordx3
+#endif
     if (padded) a.coef = tile->dev_padded;
     const dim3 grid((unsigned)blocks), block(256);
     // 3-D tile and enough points: chunks taken in z-plane order (see plane_sorted_points_kernel)
