@@ -77,6 +77,7 @@ struct MbArgs {
     int nbx, nby, nbz;
     int all_full;  // every brick lies wholly inside the lattice: no store of a plane is ever skipped
     int debug;     // WN_TUNE_ENV builds: WN_MBP_DEBUG probes (0 in the product)
+    int permute, even_permille; // WN_TUNE_ENV builds: work-distribution experiments (0 / 500 in the product)
     MbBand band[kMaxNB];
     int pass_band[kPasses]; // -1: no such pass; passes are dealt in band order, a band's passes are consecutive
 };
@@ -134,10 +135,38 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
     // bricks mostly share their column (bx, by), so a band's coefficient box only moves by 0..2 rows in z between them
     const int nyz = a.nby * a.nbz;
     const long long total = (long long)a.nbx * nyz;
-    const int item0 = (int)(total * blockIdx.x / gridDim.x), item1 = (int)(total * (blockIdx.x + 1) / gridDim.x);
+    int item0 = (int)(total * blockIdx.x / gridDim.x), item1 = (int)(total * (blockIdx.x + 1) / gridDim.x);
+#ifdef WN_TUNE_ENV
+    // experiments (profiles/r03_workgroup_end_times.txt): which workgroup -- workgroup w runs on XCD w mod 8 -- takes which range
+    if (a.permute >= 10 && a.permute < 18 && gridDim.x == 256) { // range rotl8(w, permute - 10)
+        const int r = a.permute - 10;
+        const unsigned w = ((blockIdx.x << r) | (blockIdx.x >> (8 - r))) & 255u;
+        item0 = (int)(total * w / gridDim.x);
+        item1 = (int)(total * (w + 1) / gridDim.x);
+    }
+    if (a.even_permille != 500 && (gridDim.x & 1) == 0) { // uneven shares of a pair's bricks for its even / odd workgroup
+        const int pair = blockIdx.x >> 1;
+        const int p0 = (int)(total * (2 * pair) / gridDim.x), p1 = (int)(total * (2 * pair + 2) / gridDim.x);
+        const int mid = p0 + (int)((long long)(p1 - p0) * a.even_permille / 1000);
+        item0 = (blockIdx.x & 1) ? mid : p0;
+        item1 = (blockIdx.x & 1) ? p1 : mid;
+    }
+#endif
     const int nb = item1 - item0;
     if (nb <= 0) return;
     const int G = nb * kBZ; // planes this workgroup produces
+#ifdef WN_TUNE_ENV
+    if (a.debug == 12 && blockIdx.x == 0 && tid == 0) { // shader clock of this launch: cycles and 100 MHz ticks, start / end
+        g_mbp_stamps[0] = __builtin_amdgcn_s_memtime();
+        g_mbp_stamps[1] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (a.debug == 13 && tid == 0 && blockIdx.x < 256) { // every workgroup: start / end in 100 MHz ticks, its XCC
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_mbp_stamps[blockIdx.x * 3] = __builtin_amdgcn_s_memrealtime();
+        g_mbp_stamps[blockIdx.x * 3 + 2] = xcc & 15;
+    }
+#endif
 
     struct Brick { int bx, by, bz; };
     auto brick_of = [&](int item) {
@@ -484,6 +513,13 @@ __global__ __launch_bounds__(64 * kWaves) void grid3d_mbp_kernel(const MbArgs a)
             MBP_STAMP(2);
             lds_barrier();
         }
+#ifdef WN_TUNE_ENV
+        if (a.debug == 12 && blockIdx.x == 0 && tid == 0) {
+            g_mbp_stamps[2] = __builtin_amdgcn_s_memtime();
+            g_mbp_stamps[3] = __builtin_amdgcn_s_memrealtime();
+        }
+        if (a.debug == 13 && tid == 0 && blockIdx.x < 256) g_mbp_stamps[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
     } else {
         // ---- store waves ---------------------------------------------------------------------------------------------
         const int sw = wave - (kWW + kPW);
@@ -661,6 +697,7 @@ int multiband_try(const wn_tile *tile, const GridArgs &g, int nbands, const floa
     if (g.nx <= 256 || (g.nx & 3) || g.ny <= 0 || g.nz <= 0 || g.z_const_mode || g.z0 < 0) return WN_OK;
     if (reinterpret_cast<uintptr_t>(out_dev) & 15) return WN_OK;
     MbArgs a{};
+    a.even_permille = 500;
     const double imax = std::max<double>(std::max(g.nx, g.ny), (double)g.z0 + g.nz);
     int passes = 0, box_off = 0;
     for (int w = 0; w < kPasses; ++w) a.pass_band[w] = -1;
@@ -690,6 +727,8 @@ int multiband_try(const wn_tile *tile, const GridArgs &g, int nbands, const floa
     if (box_off > kBoxFloats) return WN_OK;
 #ifdef WN_TUNE_ENV
     if (const char *e = getenv("WN_MBP_DEBUG")) a.debug = atoi(e);
+    if (const char *e = getenv("WN_MBP_EVEN_SHARE")) a.even_permille = atoi(e);
+    if (const char *e = getenv("WN_MBP_PERMUTE")) a.permute = atoi(e);
 #endif
     const size_t lds = (size_t)(2 * kRPlane + kRingFloats) * sizeof(float);
     a.coef = tile->dev;
