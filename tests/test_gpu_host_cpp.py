@@ -1,7 +1,8 @@
 """GPU: the C++ host classes (reference class names over the C ABI) and the tools built on them.
 
  * tools/gridgen               -- experient/main.cpp's role with batched launches
- * tools/scalar_api_check      -- the SCALAR members (evaluate*, noise, value), one launch each
+ * tools/scalar_api_check      -- the SCALAR members (evaluate*, noise, value): the host evaluators (default) and the
+   resident scalar kernel (WN_SCALAR_ON_DEVICE=1), both against the reference's vectors and the batched kernels
  * build/linkcheck/experient_main -- the REFERENCE'S OWN experient/main.cpp compiled against this
    repo's headers (built by `make linkcheck` in the build container; the binary travels, the
    source does not): its 15 outputs must be byte-identical to the reference's committed raws.
@@ -58,11 +59,20 @@ def test_gridgen_fast_path(tmp_path, shas):
                 assert sha(tmp_path / "raw" / f) == shas[f], f
 
 
-def test_scalar_members_match_reference_vectors(gold):
+def scalar_env(on_device):
+    env = dict(os.environ)
+    env.pop("WN_SCALAR_ON_DEVICE", None)
+    if on_device:
+        env["WN_SCALAR_ON_DEVICE"] = "1"
+    return env
+
+
+@pytest.mark.parametrize("on_device", [False, True], ids=["host_evaluators", "resident_scalar_kernel"])
+def test_scalar_members_match_reference_vectors(gold, on_device):
     exe = os.path.join(PKG, "tools", "scalar_api_check")
     pts = gold["probe_pts"][:200]
     text = f"{len(pts)}\n" + "\n".join(" ".join(repr(float(v)) for v in p) for p in pts) + "\n"
-    out = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=300, env=scalar_env(on_device))
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().split("\n")
     vals = np.array([[float(x) for x in ln.split()] for ln in lines[:len(pts)]])
@@ -85,11 +95,12 @@ def test_scalar_members_match_reference_vectors(gold):
     assert lines[len(pts) + 3].split() == ["tile", "128", "coeffs", str(128 ** 3)]
 
 
-def test_reference_experient_main_linked_against_this_library(tmp_path, shas):
+@pytest.mark.parametrize("on_device", [False, True], ids=["host_evaluators", "resident_scalar_kernel"])
+def test_reference_experient_main_linked_against_this_library(tmp_path, shas, on_device):
     exe = os.path.join(PKG, "build", "linkcheck", "experient_main")
     if not os.path.exists(exe):
         pytest.skip("build/linkcheck/experient_main not built (needs /root/reference at build time)")
-    out = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=900, env=scalar_env(on_device))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     for octave in (3, 4, 5):
         for n in NAMES:
@@ -98,9 +109,10 @@ def test_reference_experient_main_linked_against_this_library(tmp_path, shas):
 
 
 def test_scalar_calls_through_the_resident_kernel_latency_and_parity():
-    """The reference's scalar members are served by a resident one-wave kernel (csrc/wn_mailbox.hip): every value
-    equals the batched kernels' (bit for bit), a call costs microseconds instead of a launch + synchronise, and an
-    idle gap (the kernel ends by itself after 2 ms) is survived by restarting it."""
+    """With WN_SCALAR_ON_DEVICE=1 (the tool sets it) the reference's scalar members are served by a resident one-wave kernel
+    (csrc/wn_mailbox.hip): every value equals the batched kernels' (bit for bit), a call costs microseconds instead of a
+    launch + synchronise, and an idle gap (the kernel ends by itself after 2 ms) is survived by restarting it.  The host
+    evaluator (the default) is timed and compared beside it."""
     exe = os.path.join(PKG, "tools", "scalar_latency")
     assert os.path.exists(exe), "run __graft_entry__.build()"
     out = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=300)
@@ -111,4 +123,5 @@ def test_scalar_calls_through_the_resident_kernel_latency_and_parity():
     # latencies are recorded (profiles/r0*_scalar_latency.json), not asserted: wall-clock bounds on a shared box fail
     # without any code change (round-2 ADVICE); what must hold is an order of magnitude
     assert line["mailbox_us_per_call"] < 100.0, line
+    assert line["host_evaluator_us_per_call"] < line["mailbox_us_per_call"], line
     print(line)

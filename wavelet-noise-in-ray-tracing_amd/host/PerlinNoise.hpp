@@ -6,6 +6,7 @@
 #include <random>
 #include <vector>
 
+#include "scalar_eval.h"
 #include "wn_host.hpp"
 
 class PerlinNoise {
@@ -25,6 +26,7 @@ class PerlinNoise {
 
     double noise(double x, double y, double z) const // PerlinNoise.hpp:36-56
     {
+        if (!wnhost_scalar_on_device()) return wnhost_perlin(p.data(), x, y, z); // one sample: on the host (scalar_eval.h)
         double v = 0.0;
         wnhost::check(wn_scalar_perlin(perm_, x, y, z, &v), "wn_scalar_perlin");
         return v;

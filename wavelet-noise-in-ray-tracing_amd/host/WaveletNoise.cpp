@@ -1,10 +1,12 @@
-// WaveletNoise.cpp -- host side of class WaveletNoise over libwnoise_hip.so.  No noise
-// arithmetic here: tile filtering and every evaluation are HIP kernels behind include/wnoise.h.
+// WaveletNoise.cpp -- host side of class WaveletNoise over libwnoise_hip.so: tile filtering and every evaluation of
+// more than one sample are HIP kernels behind include/wnoise.h; the scalar members (one sample, needed at once) are
+// evaluated where the caller is (scalar_eval.h), or by the resident scalar kernel with WN_SCALAR_ON_DEVICE=1.
 #include "WaveletNoise.h"
 
 #include <algorithm>
 #include <cmath>
 
+#include "scalar_eval.h"
 #include "wn_host.hpp"
 
 using wnhost::check;
@@ -31,6 +33,7 @@ void WaveletNoise::generate(int dims)
     tile_ = t;
     noiseCoefficients.resize(count);
     check(wn_tile_download(tile_, noiseCoefficients.data()), "wn_tile_download");
+    tileDims = dims;
 }
 
 void WaveletNoise::generateNoiseTile2D() { generate(2); }
@@ -42,9 +45,13 @@ const wn_tile *WaveletNoise::tile(int dims) const
     return tile_;
 }
 
-// ---- scalar members: one request each to the resident scalar kernel (wn_scalar_*, include/wnoise.h) ---
+// ---- scalar members: evaluated on the host from the mirrored coefficients (scalar_eval.h; bit-identical to the kernels), or one
+// request each to the resident scalar kernel (wn_scalar_*, include/wnoise.h) with WN_SCALAR_ON_DEVICE=1.  A tile of the other
+// dimension goes to the C ABI either way, which reports it.
 float WaveletNoise::evaluate2D(const float p[2]) const
 {
+    if (!wnhost_scalar_on_device() && tileDims != 3)
+        return wnhost_eval2d(noiseCoefficients.empty() ? nullptr : noiseCoefficients.data(), tileSizeN, p);
     float v = 0.0f;
     check(wn_scalar_eval2d(tile(2), p, &v), "wn_scalar_eval2d");
     return v;
@@ -52,6 +59,8 @@ float WaveletNoise::evaluate2D(const float p[2]) const
 
 float WaveletNoise::evaluate3D(const float p[3]) const
 {
+    if (!wnhost_scalar_on_device() && tileDims != 2)
+        return wnhost_eval3d(noiseCoefficients.empty() ? nullptr : noiseCoefficients.data(), tileSizeN, p);
     float v = 0.0f;
     check(wn_scalar_eval3d(tile(3), p, &v), "wn_scalar_eval3d");
     return v;
@@ -59,6 +68,8 @@ float WaveletNoise::evaluate3D(const float p[3]) const
 
 float WaveletNoise::evaluate3DProjected(const float p[3], const float normal[3]) const
 {
+    if (!wnhost_scalar_on_device() && tileDims != 2)
+        return wnhost_eval3d_projected(noiseCoefficients.empty() ? nullptr : noiseCoefficients.data(), tileSizeN, p, normal);
     float v = 0.0f;
     check(wn_scalar_eval3d_projected(tile(3), p, normal, &v), "wn_scalar_eval3d_projected");
     return v;

@@ -6,9 +6,10 @@
 //                            exactly as the reference draws it (libstdc++ stream), filter passes
 //                            on the GPU (wn_tile_generate_from_field); coefficients stay
 //                            resident in HBM and are mirrored for getNoiseCoefficients().
-//   evaluate2D/3D/3DProjected(p) : one request to the resident scalar kernel per call (wn_scalar_*,
-//                            ~4 us, bit-identical to the reference); the batched overloads below are
-//                            the fast path.
+//   evaluate2D/3D/3DProjected(p) : one sample, on the host from the mirrored coefficients (scalar_eval.h,
+//                            bit-identical to the reference and to the kernels; WN_SCALAR_ON_DEVICE=1: one
+//                            request to the resident scalar kernel, ~2.6 us); the batched overloads below
+//                            are the GPU path.
 #ifndef WAVELET_NOISE_H
 #define WAVELET_NOISE_H
 
@@ -72,6 +73,7 @@ class WaveletNoise {
     std::mt19937 rng;
     std::normal_distribution<float> gaussianDist;
     mutable wn_tile *tile_;
+    int tileDims = 0; // dimension of the generated tile (0: none yet)
     void generate(int dims);
 };
 

@@ -2,8 +2,9 @@
 //
 // Same constructor and members; the permutation table is built on the host by the same libstdc++
 // calls as the reference (iota + std::shuffle(mt19937(seed)), perlin.h:34-39, via
-// wn_perm_create_seeded) and lives on the device as 512 bytes.  noise / fractal_noise run as HIP
-// kernels in fp64 with the reference's operation order: results are bit-identical.
+// wn_perm_create_seeded) and lives on the device as 512 bytes.  The batched forms run as HIP kernels in fp64 with the
+// reference's operation order; the scalar members are evaluated on the host from the mirrored table (scalar_eval.h;
+// WN_SCALAR_ON_DEVICE=1: by the resident scalar kernel).  Bit-identical either way.
 // Additive: turb() (RTOW; absent from the reference) and batched overloads.
 #ifndef PERLIN_H
 #define PERLIN_H
@@ -12,6 +13,7 @@
 #include <random>
 #include <vector>
 
+#include "scalar_eval.h"
 #include "vec3.h"
 #include "wn_host.hpp"
 
@@ -22,9 +24,10 @@ class perlin {
     std::vector<int> p; // host mirror of the table (perlin.h:16)
     wn_perm *perm_ = nullptr;
 
-    double scalar(const point3 &q, int kind, int depth) const // one request to the resident scalar kernel
+    double scalar(const point3 &q, int kind, int depth) const // kind 1: turb, 2: fractal_noise
     {
         const float xyz[3] = {q.x(), q.y(), q.z()};
+        if (!wnhost_scalar_on_device()) return kind == 1 ? wnhost_perlin_turb(p.data(), xyz, depth) : wnhost_perlin_fractal(p.data(), xyz);
         double v = 0.0;
         wnhost::check(wn_scalar_perlin_vec3(perm_, xyz, kind, depth, &v), "wn_scalar_perlin_vec3");
         return v;
@@ -43,6 +46,7 @@ class perlin {
     // perlin.h:42-62
     double noise(double x, double y, double z) const noexcept(false)
     {
+        if (!wnhost_scalar_on_device()) return wnhost_perlin(p.data(), x, y, z);
         double v = 0.0;
         wnhost::check(wn_scalar_perlin(perm_, x, y, z, &v), "wn_scalar_perlin");
         return v;

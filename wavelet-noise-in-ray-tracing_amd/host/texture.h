@@ -1,10 +1,10 @@
 // texture.h -- the reference's texture adaptor (texture.h:14-115) over the MI355X C ABI.
 //
 // Same class names, constructors and `value(u, v, p)` signature, so material.h / main.cpp of the
-// reference compile against this header unchanged.  value() is one request to the resident scalar
-// kernel per call (wn_scalar_*, ~4 us) and returns the reference's colour bit for bit; values() is the batched form a renderer should
-// use (hit points in, grey levels out, optional per-hit `active` bytes compacted with wavefront
-// ballots on the device).
+// reference compile against this header unchanged.  value() is one sample, evaluated on the host (scalar_eval.h;
+// WN_SCALAR_ON_DEVICE=1: one request to the resident scalar kernel, ~2.6 us) and returns the reference's colour bit for
+// bit; values() is the batched GPU form a renderer should use (hit points in, grey levels out, optional per-hit `active`
+// bytes compacted with wavefront ballots on the device).
 #ifndef TEXTURE_H
 #define TEXTURE_H
 
@@ -14,6 +14,7 @@
 
 #include "WaveletNoise.h"
 #include "perlin.h"
+#include "scalar_eval.h"
 #include "vec3.h"
 #include "wn_host.hpp"
 
@@ -64,7 +65,12 @@ class noise_texture : public texture {
     color value(double, double, const point3 &p) const override // texture.h:37-43
     {
         const float xyz[3] = {p.x(), p.y(), p.z()};
-        float g = 0.0f; // one request to the resident scalar kernel (include/wnoise.h, wn_scalar_*)
+        float g = 0.0f;
+        if (!wnhost_scalar_on_device()) { // one sample: on the host (scalar_eval.h)
+            g = wnhost_noise_texture_value(noise.table().data(), scale, octave_level, xyz);
+            return color(g, g, g);
+        }
+        // WN_SCALAR_ON_DEVICE=1: one request to the resident scalar kernel (include/wnoise.h, wn_scalar_*)
         wnhost::check(wn_scalar_noise_texture(noise.perm(), scale, octave_level, xyz, &g), "wn_scalar_noise_texture");
         return color(g, g, g);
     }
@@ -109,6 +115,13 @@ class wavelet_texture : public texture {
         const float xyz[3] = {p.x(), p.y(), p.z()};
         const bool three = use_3d_noise && noise_3d;
         float g = 0.0f;
+        if (!wnhost_scalar_on_device()) { // one sample: on the host (scalar_eval.h)
+            const WaveletNoise *src = three ? noise_3d.get() : noise_2d.get();
+            const std::vector<float> *c = src ? &src->getNoiseCoefficients() : nullptr;
+            g = wnhost_wavelet_texture_value(c && !c->empty() ? c->data() : nullptr, src ? src->getTileSize() : 0, three ? 1 : 0,
+                                             scale, octave_level, xyz);
+            return color(g, g, g);
+        }
         wnhost::check(wn_scalar_wavelet_texture(source(three), three ? 1 : 0, scale, octave_level, xyz, &g),
                       "wn_scalar_wavelet_texture");
         return color(g, g, g);

@@ -1,9 +1,10 @@
 // wn_host.hpp -- glue shared by the host classes: error translation, a per-thread pinned scratch
 // (batch-of-one calls for the few members without a wn_scalar_* entry point) and a device buffer.
 //
-// There is no CPU arithmetic in the host classes: every evaluation, scalar or batched, runs on
-// the GPU through libwnoise_hip.so (include/wnoise.h).  A failing ABI call (most commonly: no
-// HIP device) throws std::runtime_error with wn_last_error(); nothing falls back to the CPU.
+// Everything that takes more than one sample -- point lists, textures' values(), dense grids, tile generation -- runs on
+// the GPU through libwnoise_hip.so (include/wnoise.h); a failing ABI call (most commonly: no HIP device) throws
+// std::runtime_error with wn_last_error(), nothing falls back to the CPU.  Only the reference's scalar members (one sample
+// per call) are evaluated on the host (scalar_eval.h), from the mirrors the classes already keep.
 #pragma once
 
 #include <cstddef>
@@ -21,7 +22,8 @@ inline void check(int rc, const char *what)
 
 // Pinned, device-mapped staging for batch-of-one calls (WMultibandNoise): the kernel reads the point from and
 // writes the result to host memory, so such a call is launch + sync, with no memcpy calls.  The reference's own
-// scalar members (evaluate*, noise, value) use the resident scalar kernel instead (wn_scalar_*, include/wnoise.h).
+// scalar members (evaluate*, noise, value) are evaluated on the host (scalar_eval.h) or, with WN_SCALAR_ON_DEVICE=1, by the
+// resident scalar kernel (wn_scalar_*, include/wnoise.h).
 class Scratch {
   public:
     static Scratch &get()

@@ -1,10 +1,11 @@
-// scalar_latency.cpp -- what one scalar call of the reference's API costs on this library: the resident
-// scalar kernel (wn_scalar_*, csrc/wn_mailbox.hip) against the launch-plus-synchronise form it replaces
-// (a batch of one through wn_eval3d_points), and the restart after an idle gap.
+// scalar_latency.cpp -- what one scalar call of the reference's API costs on this library when it is sent to the device
+// (WN_SCALAR_ON_DEVICE=1, set by this tool): the resident scalar kernel (wn_scalar_*, csrc/wn_mailbox.hip) against the
+// launch-plus-synchronise form it replaces (a batch of one through wn_eval3d_points), and the restart after an idle gap --
+// and, beside it, the host evaluator the classes use by default (host/scalar_eval.h).
 //
 //   scalar_latency [calls=20000]
 // stdout: one JSON line {"mailbox_us_per_call":…, "launch_sync_us_per_call":…, "after_idle_us":…,
-//                        "texture_us_per_call":…, "perlin_us_per_call":…, "mismatches":0, …}
+//                        "texture_us_per_call":…, "perlin_us_per_call":…, "host_evaluator_us_per_call":…, "mismatches":0, …}
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +22,7 @@ static double now_us()
 int main(int argc, char **argv)
 {
     const int calls = argc > 1 ? std::atoi(argv[1]) : 20000;
+    setenv("WN_SCALAR_ON_DEVICE", "1", 1); // read once, at the first scalar call
     try {
         WaveletNoise n3(128, 12345);
         n3.generateNoiseTile3D();
@@ -70,12 +72,17 @@ int main(int argc, char **argv)
         double dacc = 0;
         for (int i = 0; i < calls; ++i) dacc += per.noise((double)pts[3 * i], (double)pts[3 * i + 1], (double)pts[3 * i + 2]);
         const double pn = (now_us() - t0) / calls;
+        // the default of the classes: the same sample on the host (bit-identical)
+        t0 = now_us();
+        const std::vector<float> &coef = n3.getNoiseCoefficients();
+        for (int i = 0; i < calls; ++i) bad += wnhost_eval3d(coef.data(), n3.getTileSize(), &pts[3 * i]) != batched[i];
+        const double host_eval = (now_us() - t0) / calls;
         unsigned long long served = 0, launches = 0;
         wn_scalar_stats(&served, &launches);
         std::printf("{\"calls\": %d, \"mailbox_us_per_call\": %.3f, \"launch_sync_us_per_call\": %.3f, \"after_idle_us\": %.1f, "
-                    "\"texture_us_per_call\": %.3f, \"perlin_us_per_call\": %.3f, \"mismatches\": %zu, "
+                    "\"texture_us_per_call\": %.3f, \"perlin_us_per_call\": %.3f, \"host_evaluator_us_per_call\": %.4f, \"mismatches\": %zu, "
                     "\"scalar_calls_served\": %llu, \"resident_kernel_instances\": %llu, \"checksum\": %.6g}\n",
-                    calls, mailbox, launch_sync, idle_sum / 10, tex, pn, bad, served, launches, (double)acc + dacc);
+                    calls, mailbox, launch_sync, idle_sum / 10, tex, pn, host_eval, bad, served, launches, (double)acc + dacc);
         return bad ? 1 : 0;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "scalar_latency: %s\n", e.what());
