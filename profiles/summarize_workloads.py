@@ -18,7 +18,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_OF = {  # substring of the dominant kernel's name per workload
     "perlin": "perlin_grid", "turb7": "perlin_grid", "multiband5": "grid3d_mbp_kernel<5",
-    "texture_points": "plane_sorted_points_kernel", "texture_points_perlin": "noise_texture_kernel",
+    "texture_points": "row_slab_points_kernel", "texture_points_perlin": "noise_texture_kernel",
     "wavelet3d": "grid3d_mbp_kernel<1", "wavelet3d_exact": "grid3d_exact_lds_kernel",
     "wavelet3d_1024": "grid3d_mbp_kernel<1", "wavelet3d_2048x2048x256": "grid3d_mbp_kernel<1",
     "wavelet3d_512x512x64": "grid3d_strip_kernel",

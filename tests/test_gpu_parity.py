@@ -361,6 +361,45 @@ def test_texture_plane_sorted_chunks_match_stream_order(wn):
         assert (bits(whole) == bits(pieces)).all()
 
 
+def test_row_slab_kernel_long_lists_bit_exact(wn, noise3, ora, tile3d_128):
+    """Lists of >= 2 M points on the padded 128^3 tile go through row_slab_points_kernel (wn_wavelet_points.hip): persistent
+    workgroups that keep the two y rows most of a chunk's points share in LDS and take those points' first two row triples
+    from there.  Same floats as the plain kernels (the same points in pieces below every threshold) and as the oracle, for
+    streams that (a) lie mostly on one axis-aligned plane, (b) move from one plane to another and then scatter (the slab
+    is replaced, then unused), (c) carry an `active` mask, (d) are coherent already."""
+    rng = np.random.default_rng(5)
+    n = 2 * 256 * 4096 + 3333
+    tex = wn.wavelet_texture(1.0, 4, True)
+    quad = np.stack([rng.uniform(-10, 10, n), np.full(n, -0.5), rng.uniform(-10, 10, n)], 1)
+    sph = rng.normal(size=(n, 3))
+    sph = 0.5 * sph / np.linalg.norm(sph, axis=1, keepdims=True) + [1.0, 0.0, -1.75]
+    scene = np.where((rng.uniform(size=n) < 0.85)[:, None], quad, sph).astype(np.float32)  # configs[3]'s stand-in
+    moving = quad.copy()
+    moving[n // 3: 2 * n // 3, 1] = 1.3
+    moving[2 * n // 3:, 1] = rng.uniform(-10, 10, n - 2 * n // 3)
+    moving = moving.astype(np.float32)
+    coherent = np.stack([np.linspace(-10, 10, n), np.full(n, -0.5), np.repeat(rng.uniform(-10, 10, n // 512 + 1), 512)[:n]], 1).astype(np.float32)
+    step = 30000
+    for pts in (scene, moving, coherent):
+        whole = host(tex.grey(pts))
+        pieces = np.concatenate([host(tex.grey(pts[i:i + step])) for i in range(0, n, step)])
+        assert (bits(whole) == bits(pieces)).all()
+        pick = rng.integers(0, n, 3000)
+        assert (bits(whole[pick]) == bits(ora.wavelet_texture_value(tile3d_128, True, 1.0, 4, pts[pick]))).all()
+    # masked: inactive points keep the caller's value
+    active = (rng.uniform(size=n) < 0.6).astype(np.uint8)
+    out = torch.full((n,), -7.0, dtype=torch.float32, device="cuda")
+    got = host(tex.grey(scene, active, out=out))
+    want = np.where(active != 0, host(tex.grey(scene)), np.float32(-7.0))
+    assert (bits(got) == bits(want)).all()
+    # WaveletNoise::evaluate3D lists take the same kernel (lattice coordinates: the plane y = 16.0)
+    lat = (scene * np.float32(32.0)).astype(np.float32)
+    whole = host(noise3.evaluate3D(lat))
+    pieces = np.concatenate([host(noise3.evaluate3D(lat[i:i + step])) for i in range(0, n, step)])
+    assert (bits(whole) == bits(pieces)).all()
+    assert (bits(whole[:3000]) == bits(ora.evaluate3d(tile3d_128, lat[:3000]))).all()
+
+
 @pytest.mark.parametrize("seed", (2024, 7, 31337))
 def test_dispatcher_fuzz_default_kernels_vs_exact(wn, noise3, seed):
     """Random lattices through wn_eval3d_grid / wn_multiband3d_grid: whatever kernel the dispatcher picks (strip march,

@@ -76,6 +76,62 @@ __device__ __forceinline__ float eval3d_exact(const float *coef, int n, int nmas
     return result;
 }
 
+// evaluate3D on the padded tile with two of its y rows held in LDS: `slab` = [z][2][n + 2], the rows (ry - 1) mod n and ry of
+// every z plane.  A point whose middle y row is ry takes its first two row triples (fy = 0, 1 of every fz) from the slab and
+// the third from memory -- 3 scattered 12-byte gathers instead of 9; any other point takes all nine from memory.  Same
+// values, products, sums and order as eval3d_exact<true>: the same bits.
+// `third` = [z][n + 2]: row (ry + 1) mod n of the planes z < third_planes (0: none), also in LDS.
+__device__ __forceinline__ float eval3d_exact_rowslab(const float *coef, int n, int nmask, float px, float py, float pz,
+                                                      const float *slab, int ry, const float *third, int third_planes)
+{
+    if (n == 0) return 0.0f;
+    int mx, my, mz;
+    float wx[3], wy[3], wz[3];
+    bspline(px, mx, wx[0], wx[1], wx[2]);
+    bspline(py, my, wy[0], wy[1], wy[2]);
+    bspline(pz, mz, wz[0], wz[1], wz[2]);
+    const int stride = n + 2;
+    // (the tile size is a power of two here: the wrap is a mask, and no branch on the kind of modulo splits the loads below
+    // into basic blocks)
+    const int cx0 = (mx - 1) & nmask;
+    int ry3[3], rz3[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        ry3[f] = (my + f - 1) & nmask;
+        rz3[f] = (mz + f - 1) & nmask;
+    }
+    const bool in_slab = ry3[1] == ry; // then ry3[0] is the slab's first row
+    float c[3][3][3];
+    // every load is requested before the first product; ONE divergent branch (the lanes off the slab's rows)
+#pragma unroll
+    for (int fz = 0; fz < 3; ++fz) {
+        if (in_slab && rz3[fz] < third_planes) __builtin_memcpy(c[fz][2], third + rz3[fz] * stride + cx0, 12);
+        else __builtin_memcpy(c[fz][2], coef + cx0 + ry3[2] * stride + rz3[fz] * stride * n, 12);
+    }
+    if (in_slab) {
+#pragma unroll
+        for (int fz = 0; fz < 3; ++fz)
+#pragma unroll
+            for (int fy = 0; fy < 2; ++fy) __builtin_memcpy(c[fz][fy], slab + (rz3[fz] * 2 + fy) * stride + cx0, 12);
+    } else {
+#pragma unroll
+        for (int fz = 0; fz < 3; ++fz)
+#pragma unroll
+            for (int fy = 0; fy < 2; ++fy) __builtin_memcpy(c[fz][fy], coef + cx0 + ry3[fy] * stride + rz3[fz] * stride * n, 12);
+    }
+    float result = 0.0f;
+#pragma unroll
+    for (int fz = 0; fz < 3; ++fz)
+#pragma unroll
+        for (int fy = 0; fy < 3; ++fy)
+#pragma unroll
+            for (int fx = 0; fx < 3; ++fx) {
+                const float weight = wx[fx] * wy[fy] * wz[fz];
+                result += weight * c[fz][fy][fx];
+            }
+    return result;
+}
+
 // WaveletNoise::evaluate3DProjected, WaveletNoise.cpp:218-265: data-dependent support box,
 // `break` on the first axis outside the basis support, contributions <= 1e-6 skipped.
 __device__ __forceinline__ float projected_exact(const float *coef, int n, int nmask,

@@ -36,6 +36,22 @@ __device__ __forceinline__ float wavelet_texture_value(const A &a, float px, flo
     return (float)(0.5 * (1.0 + c));                              // texture.h:104-106
 }
 
+// wavelet_texture::value on a 3-D padded tile with a two-row slab in LDS (eval3d_exact_rowslab): the same arithmetic.
+template <typename A>
+__device__ __forceinline__ float wavelet_texture_value_rowslab(const A &a, float px, float py, float pz, const float *slab, int ry,
+                                                               const float *third, int third_planes)
+{
+    float pos[3] = {(float)((double)px * a.scale), (float)((double)py * a.scale), (float)((double)pz * a.scale)};
+    pos[0] *= a.octave_mul;
+    pos[1] *= a.octave_mul;
+    pos[2] *= a.octave_mul;
+    double v = (double)eval3d_exact_rowslab(a.coef, a.n, a.nmask, pos[0], pos[1], pos[2], slab, ry, third, third_planes);
+    v *= (double)a.inv_stddev;
+    const double q = v / 4.0;
+    const double c = (q < -1.0) ? -1.0 : ((1.0 < q) ? 1.0 : q);
+    return (float)(0.5 * (1.0 + c));
+}
+
 // noise_texture::value, texture.h:37-43: scaled_p = p * scale * octave_scale in float (vec3 * float,
 // vec3.h:82-84), noise in fp64, 0.5 * (1 + n).
 template <typename Table>

@@ -305,12 +305,28 @@ struct TextureOps {
         return mid_of(p);
     }
     __device__ int mid_z(size_t i) const { return mid(a.pts[3 * i + 2]); }
+    __device__ int mid_y(size_t i) const { return mid(a.pts[3 * i + 1]); }
     __device__ int mid_x(size_t i) const { return mid(a.pts[3 * i]); }
     __device__ float eval(size_t i) const
     {
         const float *p = a.pts + 3 * i;
         return wavelet_texture_value<PADDED>(a, p[0], p[1], p[2]);
     }
+    __device__ float eval_rowslab(size_t i, const float *slab, int ry) const // padded 3-D tile only
+    {
+        const float *p = a.pts + 3 * i;
+        return wn::wavelet_texture_value_rowslab(a, p[0], p[1], p[2], slab, ry, slab, 0); // (no third row: the plane-ordered path)
+    }
+    __device__ const float *point(size_t i) const { return a.pts + 3 * i; }
+    __device__ float eval_rowslab_at(float x, float y, float z, const float *slab, int ry, const float *third, int third_planes) const
+    {
+        return wn::wavelet_texture_value_rowslab(a, x, y, z, slab, ry, third, third_planes);
+    }
+    __device__ const float *padded_tile() const { return a.coef; }
+    __device__ int tile_n() const { return a.n; }
+#ifdef WN_TUNE_ENV
+    int tune_share = 3;
+#endif
     __device__ void store(size_t i, float v) const { a.grey[i] = v; }
 };
 
@@ -323,6 +339,22 @@ struct Eval3dOps {
     __device__ float key_scale() const { return a.band_scale[a.nbands - 1]; }
     __device__ int mid_z(size_t i) const { return MULTIBAND ? mid_of(2.0f * a.pts[3 * i + 2] * key_scale()) : mid_of(a.pts[3 * i + 2]); }
     __device__ int mid_x(size_t i) const { return MULTIBAND ? mid_of(2.0f * a.pts[3 * i] * key_scale()) : mid_of(a.pts[3 * i]); }
+    __device__ int mid_y(size_t i) const { return mid_of(a.pts[3 * i + 1]); } // (single band: the row-slab kernel)
+    __device__ float eval_rowslab(size_t i, const float *slab, int ry) const  // single band, padded tile only
+    {
+        const float *p = a.pts + 3 * i;
+        return wn::eval3d_exact_rowslab(a.coef, a.n, a.nmask, p[0], p[1], p[2], slab, ry, slab, 0); // (no third row: the plane-ordered path)
+    }
+    __device__ const float *point(size_t i) const { return a.pts + 3 * i; }
+    __device__ float eval_rowslab_at(float x, float y, float z, const float *slab, int ry, const float *third, int third_planes) const
+    {
+        return wn::eval3d_exact_rowslab(a.coef, a.n, a.nmask, x, y, z, slab, ry, third, third_planes);
+    }
+    __device__ const float *padded_tile() const { return a.coef; }
+    __device__ int tile_n() const { return a.n; }
+#ifdef WN_TUNE_ENV
+    int tune_share = 3;
+#endif
     __device__ float eval(size_t i) const
     {
         const float *p = a.pts + 3 * i;
@@ -337,6 +369,207 @@ struct Eval3dOps {
     }
     __device__ void store(size_t i, float v) const { a.out[i] = v; }
 };
+
+// Long lists on a padded 128^3 tile: the plane-ordered chunks above, evaluated by persistent 1024-thread workgroups (one per
+// CU) that keep TWO y rows of every z plane of the tile in LDS (130 KiB: rows ry - 1 and ry, [z][2][n + 2]).
+// plane_sorted_points_kernel is bound by the texture addresser / L1 at one lane-access per clock and CU: nine divergent
+// 12-byte gathers per point (profiles/r03a_texture_points_ta_counters.json), 2.7x its VALU time.  Ray hits lie on surfaces;
+// on an axis-aligned one (the reference scene's ground quad y = -0.5: 85 % of its hits) every point has the same three y
+// rows.  With two of them in LDS such a point gathers 3 times from memory instead of 9 and reads the rest from LDS
+// (eval3d_exact_rowslab: same values, same order of products and sums -> the same bits); any other point gathers all nine
+// as before.  Each chunk counts its points' middle y rows beside the sort keys; when another row than the resident one holds
+// a quarter of the chunk, the workgroup loads that row pair instead (130 KiB from the L2-resident tile, ~2 us), so a stream
+// that moves from one surface to the next is followed.  No dominant row: the kernel is the plane-ordered one at the same
+// occupancy (16 waves per CU).
+constexpr int kSlabThreads = 1024, kSlabPerThread = kSortChunk / kSlabThreads, kSlabTile = 128, kSlabTrust = 7;
+constexpr size_t kSlabFloats = (size_t)kSlabTile * 2 * (kSlabTile + 2);
+constexpr size_t kSlabScratchBytes = kSortBins * 4 + kSortChunk * 4 + kSortChunk * 2;
+constexpr int kSlabThirdPlanes = (int)(kSlabScratchBytes / ((kSlabTile + 2) * 4));
+constexpr size_t kSlabLdsBytes = kSlabFloats * sizeof(float) + kSlabScratchBytes;
+constexpr size_t kSlabMinPoints = 2 * 256 * (size_t)kSortChunk; // >= two chunks per workgroup of a 256-CU device
+
+template <typename Ops>
+__global__ __launch_bounds__(kSlabThreads) void row_slab_points_kernel(const Ops ops, const int nchunks)
+{
+    static_assert(kSortBins == kSlabThreads, "one bin per thread in the prefix sum");
+    extern __shared__ __attribute__((aligned(16))) float slab[]; // [z][2][n + 2], then kSlabScratchBytes of scratch
+    // the scratch is the plane-ordered path's histogram, order and values -- or, while chunks are taken in stream order, the
+    // slab's THIRD row (ry + 1) for as many planes as fit (55 of 128): those points gather once or not at all
+    unsigned *const hist = reinterpret_cast<unsigned *>(slab + kSlabFloats);
+    float *const value = reinterpret_cast<float *>(hist + kSortBins);
+    unsigned short *const order = reinterpret_cast<unsigned short *>(value + kSortChunk);
+    float *const third = slab + kSlabFloats;
+    __shared__ unsigned rowhist[kSlabTile];
+    __shared__ unsigned s_changes, s_best, wave_total[kSlabThreads / 64];
+    bool third_ok = false; // the scratch holds the third row of the resident pair
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = ops.tile_n(), stride = n + 2; // n == kSlabTile (host)
+    int slab_row = -1;                          // row ry of the resident pair; -1: none yet
+    int trusted = 0;                            // chunks still to be taken in stream order without looking at their rows
+    // a chunk in stream order: the thread's four points are requested together, then evaluated one after the other
+    auto stream_order = [&](size_t begin, int count) {
+        float xyz[kSlabPerThread][3];
+        bool on[kSlabPerThread];
+#pragma unroll
+        for (int k = 0; k < kSlabPerThread; ++k) {
+            const int i = tid + kSlabThreads * k;
+            on[k] = i < count && ops.active(begin + i);
+            const float *p = ops.point(begin + min(i, count - 1));
+            xyz[k][0] = p[0];
+            xyz[k][1] = p[1];
+            xyz[k][2] = p[2];
+        }
+#pragma unroll
+        for (int k = 0; k < kSlabPerThread; ++k)
+            if (on[k])
+                ops.store(begin + tid + kSlabThreads * k,
+                          ops.eval_rowslab_at(xyz[k][0], xyz[k][1], xyz[k][2], slab, slab_row, third, third_ok ? kSlabThirdPlanes : 0));
+    };
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const size_t begin = (size_t)chunk * kSortChunk;
+        const int count = (int)min((size_t)kSortChunk, ops.count - begin);
+        // After a chunk that mostly read from the slab, the next kSlabTrust chunks are evaluated in stream order unseen: no
+        // histogram, no barrier, nothing written to LDS -- the waves run free.  (A point off the slab's rows gathers all nine
+        // triples, as ever: what a wrong guess costs is speed.)
+        if (trusted > 0) {
+            --trusted;
+            stream_order(begin, count);
+            continue;
+        }
+        __syncthreads(); // free-running chunks end here: the histograms are rewritten, the slab may be replaced
+        if (tid < kSlabTile) rowhist[tid] = 0;
+        if (tid == 0) {
+            s_changes = 0;
+            s_best = 0;
+        }
+        __syncthreads();
+        if (tid < 256) { // is the stream already coherent?  (as in plane_sorted_points_kernel)
+            const int k = ops.mid_z(begin + min(tid, count - 1));
+            const int prev = __shfl_up(k, 1, 64);
+            const unsigned long long diff = __ballot(lane != 0 && prev != k);
+            if (lane == 0) atomicAdd(&s_changes, (unsigned)__popcll(diff));
+        }
+        // the middle y rows of the chunk's points
+#pragma unroll
+        for (int k = 0; k < kSlabPerThread; ++k) {
+            const int i = tid + kSlabThreads * k;
+            if (i < count && ops.active(begin + i)) atomicAdd(&rowhist[ops.mid_y(begin + i) & (kSlabTile - 1)], 1u);
+        }
+        __syncthreads();
+        if (tid < kSlabTile) { // the row most points share: (count << 8 | row), largest wins
+            unsigned best = (rowhist[tid] << 8) | (unsigned)tid;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, d, 64));
+            if (lane == 0) atomicMax(&s_best, best);
+        }
+        __syncthreads();
+        const int best_row = (int)(s_best & 255u), best_count = (int)(s_best >> 8);
+        const bool reload = best_count * 4 >= count && best_row != slab_row; // workgroup-uniform
+        if (reload) { // rows best_row - 1 and best_row of every plane; the last chunk's readers passed the barrier at its end
+            const int r0 = (best_row + n - 1) & (kSlabTile - 1);
+            const float *tile = ops.padded_tile();
+            for (int i = tid; i < (int)kSlabFloats; i += kSlabThreads) {
+                const int row = i / stride, col = i - row * stride; // row = z * 2 + f
+                const int z = row >> 1, y = (row & 1) ? best_row : r0;
+                slab[i] = tile[((size_t)z * n + y) * stride + col];
+            }
+            slab_row = best_row;
+            third_ok = false;
+            __syncthreads();
+        }
+        // stream order when the stream is coherent already, or when most of the chunk reads from the slab (what is left to
+        // gather then is one row of every plane, 66 KB: the plane order buys little)
+        int slab_share_min = 3;
+#ifdef WN_TUNE_ENV
+        slab_share_min = ops.tune_share;
+#endif
+        if (s_changes < 128 || (best_row == slab_row && best_count * 4 >= count * slab_share_min)) {
+            if (!third_ok && slab_row >= 0) { // (the scratch's last users passed the barrier at the loop's top)
+                const int r2 = (slab_row + 1) & (kSlabTile - 1);
+                const float *tile = ops.padded_tile();
+                for (int i = tid; i < kSlabThirdPlanes * stride; i += kSlabThreads) {
+                    const int z = i / stride, col = i - z * stride;
+                    third[i] = tile[((size_t)z * n + r2) * stride + col];
+                }
+                third_ok = true;
+                __syncthreads();
+            }
+            stream_order(begin, count);
+            if (best_row == slab_row && best_count * 4 >= count * slab_share_min) trusted = kSlabTrust;
+            continue;
+        }
+        // pass 1: bin and rank of every point (the scratch becomes the histogram: zeroed here)
+        third_ok = false;
+        hist[tid] = 0;
+        __syncthreads();
+        unsigned short key[kSlabPerThread], rank[kSlabPerThread];
+#pragma unroll
+        for (int k = 0; k < kSlabPerThread; ++k) {
+            const int i = tid + kSlabThreads * k;
+            key[k] = 0xffff;
+            rank[k] = 0;
+            if (i < count && ops.active(begin + i)) {
+                const int bin = ((ops.mid_z(begin + i) & (kSortPlanes - 1)) << kSortXBits) | ((ops.mid_x(begin + i) & 127) >> (7 - kSortXBits));
+                key[k] = (unsigned short)bin;
+                rank[k] = (unsigned short)atomicAdd(&hist[bin], 1u);
+            }
+        }
+        __syncthreads();
+        const unsigned mine = hist[tid]; // exclusive prefix sum of the bins: one per thread
+        unsigned inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wave_total[wave] = inc;
+        __syncthreads();
+        {
+            unsigned run = inc - mine;
+            for (int w = 0; w < wave; ++w) run += wave_total[w];
+            hist[tid] = run;
+        }
+        int n_active = 0;
+#pragma unroll
+        for (int w = 0; w < kSlabThreads / 64; ++w) n_active += (int)wave_total[w];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSlabPerThread; ++k)
+            if (key[k] != 0xffff) order[hist[key[k]] + rank[k]] = (unsigned short)(tid + kSlabThreads * k);
+        __syncthreads();
+        // pass 2: evaluate in bin order; the values return to stream order in LDS and leave as full lines
+        for (int s2 = tid; s2 < n_active; s2 += kSlabThreads) {
+            const int i = order[s2];
+            value[i] = ops.eval_rowslab(begin + i, slab, slab_row);
+        }
+        __syncthreads();
+        for (int i = tid; i < count; i += kSlabThreads)
+            if (ops.active(begin + i)) ops.store(begin + i, value[i]);
+        __syncthreads(); // the next chunk zeroes the histograms and may replace the slab
+    }
+}
+
+// false: not in this kernel's regime (the caller launches plane_sorted_points_kernel)
+template <typename Ops>
+bool launch_row_slab(Ops ops, int n, hipStream_t stream)
+{
+    if (n != kSlabTile || ops.count < kSlabMinPoints) return false;
+#ifdef WN_TUNE_ENV
+    if (getenv("WN_NO_ROW_SLAB")) return false;
+#endif
+    const size_t chunks = (ops.count + kSortChunk - 1) / kSortChunk;
+    if (chunks > 0x7fffffffull) return false;
+#ifdef WN_TUNE_ENV
+    if (const char *e = getenv("WN_ROW_SLAB_SHARE")) ops.tune_share = atoi(e); // quarters of a chunk; 5: never
+#endif
+    const void *fn = reinterpret_cast<const void *>(&row_slab_points_kernel<Ops>);
+    const int dev = wn::current_device();
+    if (!wn::ensure_dynamic_lds(fn, dev, kSlabLdsBytes)) return false; // the runtime refused the LDS opt-in
+    const int grid = (int)std::min<size_t>(chunks, (size_t)wn::device_compute_units(dev));
+    hipLaunchKernelGGL((row_slab_points_kernel<Ops>), dim3((unsigned)grid), dim3(kSlabThreads), kSlabLdsBytes, stream, ops,
+                       (int)chunks);
+    return true;
+}
 
 template <typename Ops>
 int launch_sorted(const Ops &ops, hipStream_t stream)
@@ -399,6 +632,10 @@ int wn_eval3d_points(const wn_tile *tile, const float *xyz_dev, size_t n, float 
     a.pts = xyz_dev;
     a.out = out_dev;
     if (n >= kSortMinPoints && a.n > 0 && sort_enabled()) { // long lists: chunks in z-plane order (plane_sorted_points_kernel)
+        if (tile->dev_padded && launch_row_slab(Eval3dOps<true, false>{a, n}, a.n, as_stream(stream))) {
+            WN_LAUNCH_CHECK("row_slab_points_kernel(evaluate3D)");
+            return WN_OK;
+        }
         const int lrc = tile->dev_padded ? launch_sorted(Eval3dOps<true, false>{a, n}, as_stream(stream))
                                          : launch_sorted(Eval3dOps<false, false>{a, n}, as_stream(stream));
         if (lrc) return fail(lrc, "too many points");
@@ -570,6 +807,11 @@ int wn_wavelet_texture_points(const wn_tile *tile, int use_3d, double scale, int
 #endif
     if (sorted) {
         int lrc;
+        if (padded && (active_dev ? launch_row_slab(TextureOps<true, true>{a, n}, a.n, as_stream(stream))
+                                  : launch_row_slab(TextureOps<false, true>{a, n}, a.n, as_stream(stream)))) {
+            WN_LAUNCH_CHECK("row_slab_points_kernel(texture)");
+            return WN_OK;
+        }
         if (active_dev) lrc = padded ? launch_sorted(TextureOps<true, true>{a, n}, as_stream(stream)) : launch_sorted(TextureOps<true, false>{a, n}, as_stream(stream));
         else lrc = padded ? launch_sorted(TextureOps<false, true>{a, n}, as_stream(stream)) : launch_sorted(TextureOps<false, false>{a, n}, as_stream(stream));
         if (lrc) return fail(lrc, "too many points");
