@@ -349,7 +349,7 @@ class Workload:
             self.tex_pts = pts
             self.samples = m
             self.alg_bytes = 16 * m  # 12 B xyz in + 4 B out
-            self.kernel = "noise_texture_kernel" if perlin_tex else "row_slab_points_kernel"
+            self.kernel = "noise_texture_kernel" if perlin_tex else "row_slab_points_kernel"  # (after plane_sorted_points_kernel<defer>: two launches a call)
             self.desc = f"{m} ray hit points, {'noise_texture (Perlin)' if perlin_tex else 'wavelet_texture'} octave {OCTAVE} (configs[3] stand-in)"
             self.dtype = "f64" if perlin_tex else "f32"
             if perlin_tex:

@@ -362,13 +362,15 @@ def test_texture_plane_sorted_chunks_match_stream_order(wn):
 
 
 def test_row_slab_kernel_long_lists_bit_exact(wn, noise3, ora, tile3d_128):
-    """Lists of >= 2 M points on the padded 128^3 tile go through row_slab_points_kernel (wn_wavelet_points.hip): persistent
-    workgroups that keep the two y rows most of a chunk's points share in LDS and take those points' first two row triples
-    from there.  Same floats as the plain kernels (the same points in pieces below every threshold) and as the oracle, for
-    streams that (a) lie mostly on one axis-aligned plane, (b) move from one plane to another and then scatter (the slab
-    is replaced, then unused), (c) carry an `active` mask, (d) are coherent already."""
+    """Unmasked lists of >= 16.8 M points on the padded 128^3 tile: plane_sorted_points_kernel evaluates the chunks that are
+    coherent already and leaves the others to row_slab_points_kernel (wn_wavelet_points.hip): persistent workgroups that
+    keep the two y rows most of a chunk's points share in LDS (and a third for 55 planes) and take those points' row
+    triples from there.  Same floats as the plain kernels (the same points in pieces below every threshold) and as the
+    oracle, for streams that (a) lie mostly on one axis-aligned plane, (b) move from one plane to another and then scatter
+    (the slab is replaced, then unused), (c) are coherent already, (d) carry an `active` mask (the plane-ordered kernel
+    alone)."""
     rng = np.random.default_rng(5)
-    n = 2 * 256 * 4096 + 3333
+    n = 16 * 256 * 4096 + 3333
     tex = wn.wavelet_texture(1.0, 4, True)
     quad = np.stack([rng.uniform(-10, 10, n), np.full(n, -0.5), rng.uniform(-10, 10, n)], 1)
     sph = rng.normal(size=(n, 3))
@@ -379,7 +381,7 @@ def test_row_slab_kernel_long_lists_bit_exact(wn, noise3, ora, tile3d_128):
     moving[2 * n // 3:, 1] = rng.uniform(-10, 10, n - 2 * n // 3)
     moving = moving.astype(np.float32)
     coherent = np.stack([np.linspace(-10, 10, n), np.full(n, -0.5), np.repeat(rng.uniform(-10, 10, n // 512 + 1), 512)[:n]], 1).astype(np.float32)
-    step = 30000
+    step = 60000  # < 16 chunks: the plain kernels
     for pts in (scene, moving, coherent):
         whole = host(tex.grey(pts))
         pieces = np.concatenate([host(tex.grey(pts[i:i + step])) for i in range(0, n, step)])

@@ -207,7 +207,12 @@ constexpr size_t kSortMinPoints = 16 * (size_t)kSortChunk; // shorter lists: the
 
 // The kernel is generic over what a point is (`Ops`): count; active(i); mid_z(i) / mid_x(i) = the coefficient index of the
 // z / x tap's middle (of the finest band, where there are several); eval(i); store(i, v).
-template <typename Ops>
+// A chunk left to row_slab_points_kernel is marked in the output itself: this value (a NaN no evaluation produces; if one
+// ever did, the chunk would be evaluated twice to the same floats) in the chunk's first element.
+constexpr unsigned kDeferredBits = 0xffc0de42u;
+constexpr int kDeferMarks = 16, kDeferMarkStride = 64; // row_slab_points_kernel: 16 waves, wave w stores element 64 w first
+
+template <typename Ops, bool DEFER = false>
 __global__ __launch_bounds__(256) void plane_sorted_points_kernel(const Ops ops)
 {
     constexpr int kPer = kSortBins / 256;
@@ -218,23 +223,52 @@ __global__ __launch_bounds__(256) void plane_sorted_points_kernel(const Ops ops)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t begin = (size_t)blockIdx.x * kSortChunk;
     const int count = (int)min((size_t)kSortChunk, ops.count - begin);
+    __shared__ unsigned s_rows[DEFER ? 128 : 1], s_top, s_near;
     for (int b = tid; b < kSortBins; b += 256) hist[b] = 0;
-    if (tid == 0) s_changes = 0;
+    if (tid == 0) {
+        s_changes = 0;
+        s_top = 0;
+        s_near = 0;
+    }
+    if (DEFER && tid < 128) s_rows[tid] = 0;
     __syncthreads();
     // sample (the chunk's first 256 points): do neighbours of the stream change plane?  (A second test, "... and share
     // rows", would spare lists scattered in all three dimensions the 5 % the sorting passes cost them -- 25.4 -> 24.1 G
     // points/s -- but it also turns away curved surfaces, which gain: the stand-in's sphere hits, 1.19 -> 1.34 ms.)
     {
-        const int k = ops.mid_z(begin + min(tid, count - 1));
+        const size_t si = begin + min(tid, count - 1);
+        const int k = ops.mid_z(si);
         const int prev = __shfl_up(k, 1, 64);
         const unsigned long long diff = __ballot(lane != 0 && prev != k);
         if (lane == 0) atomicAdd(&s_changes, (unsigned)__popcll(diff));
+        if constexpr (DEFER) { // ... are neighbours at least in neighbouring cells?  which middle y rows?
+            const int kx = ops.mid_x(si), prevx = __shfl_up(kx, 1, 64);
+            const unsigned long long near = __ballot(lane != 0 && abs(prev - k) <= 1 && abs(prevx - kx) <= 1);
+            if (lane == 0) atomicAdd(&s_near, (unsigned)__popcll(near));
+            atomicAdd(&s_rows[ops.mid_y(si) & 127], 1u);
+        }
     }
     __syncthreads();
     if (s_changes < 128) { // coherent already: stream order, no sorting passes
         for (int i = tid; i < count; i += 256)
             if (ops.active(begin + i)) ops.store(begin + i, ops.eval(begin + i));
         return;
+    }
+    if constexpr (DEFER) {
+        // Incoherent.  Hits scattered over an axis-aligned surface -- hardly any neighbours of the stream in neighbouring
+        // cells, three quarters of the sample on one middle y row -- are what the row-slab kernel is for: it follows on the
+        // stream and takes the chunk.  This kernel keeps every other chunk (the renderer's bounce-interleaved hits sort well:
+        // its plane-ordered path at 20 waves per CU beats the slab kernel's 16 on them).
+        if (s_near * 10 <= 256 && count == kSortChunk) { // (whole chunks only: every wave of the slab kernel has its mark)
+            if (tid < 128) atomicMax(&s_top, s_rows[tid]);
+            __syncthreads();
+            if (s_top * 4 >= 256 * 3) {
+                // (one mark per wave of that kernel, where the wave's own first store goes: its waves run through such
+                // chunks without a barrier, and a mark one wave has overwritten must not tell another that the chunk is done)
+                if (tid < kDeferMarks) ops.store(begin + kDeferMarkStride * tid, __uint_as_float(kDeferredBits));
+                return;
+            }
+        }
     }
     // pass 1: bin and rank of every point (one LDS atomic each)
     unsigned short key[kSortPerThread], rank[kSortPerThread];
@@ -328,6 +362,7 @@ struct TextureOps {
     int tune_share = 3;
 #endif
     __device__ void store(size_t i, float v) const { a.grey[i] = v; }
+    __device__ float stored(size_t i) const { return a.grey[i]; }
 };
 
 // WaveletNoise::evaluate3D per point; nbands > 0: WMultibandNoise (keyed by its finest band, the last one)
@@ -368,6 +403,7 @@ struct Eval3dOps {
         return v;
     }
     __device__ void store(size_t i, float v) const { a.out[i] = v; }
+    __device__ float stored(size_t i) const { return a.out[i]; }
 };
 
 // Long lists on a padded 128^3 tile: the plane-ordered chunks above, evaluated by persistent 1024-thread workgroups (one per
@@ -381,17 +417,20 @@ struct Eval3dOps {
 // a quarter of the chunk, the workgroup loads that row pair instead (130 KiB from the L2-resident tile, ~2 us), so a stream
 // that moves from one surface to the next is followed.  No dominant row: the kernel is the plane-ordered one at the same
 // occupancy (16 waves per CU).
-constexpr int kSlabThreads = 1024, kSlabPerThread = kSortChunk / kSlabThreads, kSlabTile = 128, kSlabTrust = 7;
+constexpr int kSlabThreads = 1024, kSlabPerThread = kSortChunk / kSlabThreads, kSlabTile = 128, kSlabTrust = 15;
 constexpr size_t kSlabFloats = (size_t)kSlabTile * 2 * (kSlabTile + 2);
 constexpr size_t kSlabScratchBytes = kSortBins * 4 + kSortChunk * 4 + kSortChunk * 2;
 constexpr int kSlabThirdPlanes = (int)(kSlabScratchBytes / ((kSlabTile + 2) * 4));
 constexpr size_t kSlabLdsBytes = kSlabFloats * sizeof(float) + kSlabScratchBytes;
-constexpr size_t kSlabMinPoints = 2 * 256 * (size_t)kSortChunk; // >= two chunks per workgroup of a 256-CU device
+// The pair of launches costs ~7 us more than plane_sorted_points_kernel alone when that kernel ends up keeping every chunk (the
+// renderer's stream: its marks are looked for in vain); from 16.8 M points that is < 5 % of the call.
+constexpr size_t kSlabMinPoints = 16 * 256 * (size_t)kSortChunk;
 
 template <typename Ops>
-__global__ __launch_bounds__(kSlabThreads) void row_slab_points_kernel(const Ops ops, const int nchunks)
+__global__ __launch_bounds__(kSlabThreads) void row_slab_points_kernel(const Ops ops, const int nchunks, const int deferred_only)
 {
     static_assert(kSortBins == kSlabThreads, "one bin per thread in the prefix sum");
+    static_assert(kDeferMarks * 64 == kSlabThreads && kDeferMarkStride == 64, "one mark per wave, at the wave's first element");
     extern __shared__ __attribute__((aligned(16))) float slab[]; // [z][2][n + 2], then kSlabScratchBytes of scratch
     // the scratch is the plane-ordered path's histogram, order and values -- or, while chunks are taken in stream order, the
     // slab's THIRD row (ry + 1) for as many planes as fit (55 of 128): those points gather once or not at all
@@ -405,7 +444,7 @@ __global__ __launch_bounds__(kSlabThreads) void row_slab_points_kernel(const Ops
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = ops.tile_n(), stride = n + 2; // n == kSlabTile (host)
     int slab_row = -1;                          // row ry of the resident pair; -1: none yet
-    int trusted = 0;                            // chunks still to be taken in stream order without looking at their rows
+    int trusted = 0, trusted_plain = 0;         // chunks still to be taken in stream order without looking at their rows
     // a chunk in stream order: the thread's four points are requested together, then evaluated one after the other
     auto stream_order = [&](size_t begin, int count) {
         float xyz[kSlabPerThread][3];
@@ -425,7 +464,22 @@ __global__ __launch_bounds__(kSlabThreads) void row_slab_points_kernel(const Ops
                 ops.store(begin + tid + kSlabThreads * k,
                           ops.eval_rowslab_at(xyz[k][0], xyz[k][1], xyz[k][2], slab, slab_row, third, third_ok ? kSlabThirdPlanes : 0));
     };
-    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    // The workgroup's chunks (blockIdx.x, + gridDim.x, ...) in groups of 64.  After plane_sorted_points_kernel<Ops, true> on
+    // the same stream only the chunks it left: a wave reads the marks of a group's chunks at once -- one load per lane, each
+    // wave the marks only it overwrites, all the same -- instead of paying a memory round trip per chunk to learn it is done.
+    for (int g0 = blockIdx.x; g0 < nchunks; g0 += 64 * (int)gridDim.x) {
+    unsigned long long todo = ~0ull;
+    if (deferred_only) {
+        const long long c = (long long)g0 + (long long)lane * gridDim.x;
+        bool left = false;
+        if (c < nchunks && ((size_t)c + 1) * kSortChunk <= ops.count) // (only whole chunks are ever left)
+            left = __float_as_uint(ops.stored((size_t)c * kSortChunk + kDeferMarkStride * wave)) == kDeferredBits;
+        todo = __ballot(left);
+    }
+    for (int j = 0; j < 64; ++j) {
+        const long long chunk = (long long)g0 + (long long)j * gridDim.x;
+        if (chunk >= nchunks) break;
+        if (!((todo >> j) & 1ull)) continue;
         const size_t begin = (size_t)chunk * kSortChunk;
         const int count = (int)min((size_t)kSortChunk, ops.count - begin);
         // After a chunk that mostly read from the slab, the next kSlabTrust chunks are evaluated in stream order unseen: no
@@ -434,6 +488,12 @@ __global__ __launch_bounds__(kSlabThreads) void row_slab_points_kernel(const Ops
         if (trusted > 0) {
             --trusted;
             stream_order(begin, count);
+            continue;
+        }
+        if (trusted_plain > 0) { // after a coherent chunk: the same for its successors, unseen
+            --trusted_plain;
+            for (int i = tid; i < count; i += kSlabThreads)
+                if (ops.active(begin + i)) ops.store(begin + i, ops.eval(begin + i));
             continue;
         }
         __syncthreads(); // free-running chunks end here: the histograms are rewritten, the slab may be replaced
@@ -449,13 +509,16 @@ __global__ __launch_bounds__(kSlabThreads) void row_slab_points_kernel(const Ops
             const unsigned long long diff = __ballot(lane != 0 && prev != k);
             if (lane == 0) atomicAdd(&s_changes, (unsigned)__popcll(diff));
         }
-        // the middle y rows of the chunk's points
-#pragma unroll
-        for (int k = 0; k < kSlabPerThread; ++k) {
-            const int i = tid + kSlabThreads * k;
-            if (i < count && ops.active(begin + i)) atomicAdd(&rowhist[ops.mid_y(begin + i) & (kSlabTile - 1)], 1u);
+        // the middle y rows of a sample of the chunk: every fourth point
+        int sampled = 0;
+        {
+            const int i = tid * kSlabPerThread;
+            if (i < count && ops.active(begin + i)) {
+                atomicAdd(&rowhist[ops.mid_y(begin + i) & (kSlabTile - 1)], 1u);
+                sampled = 1;
+            }
         }
-        __syncthreads();
+        sampled = __syncthreads_count(sampled);
         if (tid < kSlabTile) { // the row most points share: (count << 8 | row), largest wins
             unsigned best = (rowhist[tid] << 8) | (unsigned)tid;
 #pragma unroll
@@ -464,7 +527,7 @@ __global__ __launch_bounds__(kSlabThreads) void row_slab_points_kernel(const Ops
         }
         __syncthreads();
         const int best_row = (int)(s_best & 255u), best_count = (int)(s_best >> 8);
-        const bool reload = best_count * 4 >= count && best_row != slab_row; // workgroup-uniform
+        const bool reload = best_count * 4 >= sampled && sampled > 0 && best_row != slab_row; // workgroup-uniform
         if (reload) { // rows best_row - 1 and best_row of every plane; the last chunk's readers passed the barrier at its end
             const int r0 = (best_row + n - 1) & (kSlabTile - 1);
             const float *tile = ops.padded_tile();
@@ -483,7 +546,13 @@ __global__ __launch_bounds__(kSlabThreads) void row_slab_points_kernel(const Ops
 #ifdef WN_TUNE_ENV
         slab_share_min = ops.tune_share;
 #endif
-        if (s_changes < 128 || (best_row == slab_row && best_count * 4 >= count * slab_share_min)) {
+        if (s_changes < 128) { // coherent already: neighbours share their lines, plain gathers in stream order are the fastest form
+            for (int i = tid; i < count; i += kSlabThreads)
+                if (ops.active(begin + i)) ops.store(begin + i, ops.eval(begin + i));
+            trusted_plain = kSlabTrust;
+            continue;
+        }
+        if (best_row == slab_row && best_count * 4 >= sampled * slab_share_min) {
             if (!third_ok && slab_row >= 0) { // (the scratch's last users passed the barrier at the loop's top)
                 const int r2 = (slab_row + 1) & (kSlabTile - 1);
                 const float *tile = ops.padded_tile();
@@ -495,7 +564,7 @@ __global__ __launch_bounds__(kSlabThreads) void row_slab_points_kernel(const Ops
                 __syncthreads();
             }
             stream_order(begin, count);
-            if (best_row == slab_row && best_count * 4 >= count * slab_share_min) trusted = kSlabTrust;
+            if (best_row == slab_row && best_count * 4 >= sampled * slab_share_min) trusted = kSlabTrust;
             continue;
         }
         // pass 1: bin and rank of every point (the scratch becomes the histogram: zeroed here)
@@ -547,27 +616,29 @@ __global__ __launch_bounds__(kSlabThreads) void row_slab_points_kernel(const Ops
             if (ops.active(begin + i)) ops.store(begin + i, value[i]);
         __syncthreads(); // the next chunk zeroes the histograms and may replace the slab
     }
+    }
 }
 
-// false: not in this kernel's regime (the caller launches plane_sorted_points_kernel)
+// Long unmasked lists on a padded 128^3 tile: plane_sorted_points_kernel evaluates the chunks whose stream order is coherent
+// already (many small workgroups, 20 waves per CU: the renderer's primary hits run 20 % faster there than in the 16 waves of
+// the slab kernel) and leaves the others, marked, to row_slab_points_kernel, which follows on the same stream.
+// false: not in this regime (the caller launches plane_sorted_points_kernel alone).
 template <typename Ops>
-bool launch_row_slab(Ops ops, int n, hipStream_t stream)
+bool launch_row_slab(Ops ops, int n, bool masked, hipStream_t stream)
 {
-    if (n != kSlabTile || ops.count < kSlabMinPoints) return false;
+    if (n != kSlabTile || masked || ops.count < kSlabMinPoints) return false;
 #ifdef WN_TUNE_ENV
     if (getenv("WN_NO_ROW_SLAB")) return false;
+    if (const char *e = getenv("WN_ROW_SLAB_SHARE")) ops.tune_share = atoi(e); // quarters of a chunk; 5: never
 #endif
     const size_t chunks = (ops.count + kSortChunk - 1) / kSortChunk;
     if (chunks > 0x7fffffffull) return false;
-#ifdef WN_TUNE_ENV
-    if (const char *e = getenv("WN_ROW_SLAB_SHARE")) ops.tune_share = atoi(e); // quarters of a chunk; 5: never
-#endif
     const void *fn = reinterpret_cast<const void *>(&row_slab_points_kernel<Ops>);
     const int dev = wn::current_device();
     if (!wn::ensure_dynamic_lds(fn, dev, kSlabLdsBytes)) return false; // the runtime refused the LDS opt-in
     const int grid = (int)std::min<size_t>(chunks, (size_t)wn::device_compute_units(dev));
-    hipLaunchKernelGGL((row_slab_points_kernel<Ops>), dim3((unsigned)grid), dim3(kSlabThreads), kSlabLdsBytes, stream, ops,
-                       (int)chunks);
+    hipLaunchKernelGGL((plane_sorted_points_kernel<Ops, true>), dim3((unsigned)chunks), dim3(256), 0, stream, ops);
+    hipLaunchKernelGGL((row_slab_points_kernel<Ops>), dim3((unsigned)grid), dim3(kSlabThreads), kSlabLdsBytes, stream, ops, (int)chunks, 1);
     return true;
 }
 
@@ -576,7 +647,7 @@ int launch_sorted(const Ops &ops, hipStream_t stream)
 {
     const size_t blocks = (ops.count + kSortChunk - 1) / kSortChunk;
     if (blocks > 0x7fffffffull) return WN_ERR_INVALID;
-    hipLaunchKernelGGL((plane_sorted_points_kernel<Ops>), dim3((unsigned)blocks), dim3(256), 0, stream, ops);
+    hipLaunchKernelGGL((plane_sorted_points_kernel<Ops, false>), dim3((unsigned)blocks), dim3(256), 0, stream, ops);
     return WN_OK;
 }
 
@@ -632,7 +703,7 @@ int wn_eval3d_points(const wn_tile *tile, const float *xyz_dev, size_t n, float 
     a.pts = xyz_dev;
     a.out = out_dev;
     if (n >= kSortMinPoints && a.n > 0 && sort_enabled()) { // long lists: chunks in z-plane order (plane_sorted_points_kernel)
-        if (tile->dev_padded && launch_row_slab(Eval3dOps<true, false>{a, n}, a.n, as_stream(stream))) {
+        if (tile->dev_padded && launch_row_slab(Eval3dOps<true, false>{a, n}, a.n, false, as_stream(stream))) {
             WN_LAUNCH_CHECK("row_slab_points_kernel(evaluate3D)");
             return WN_OK;
         }
@@ -807,8 +878,7 @@ int wn_wavelet_texture_points(const wn_tile *tile, int use_3d, double scale, int
 #endif
     if (sorted) {
         int lrc;
-        if (padded && (active_dev ? launch_row_slab(TextureOps<true, true>{a, n}, a.n, as_stream(stream))
-                                  : launch_row_slab(TextureOps<false, true>{a, n}, a.n, as_stream(stream)))) {
+        if (padded && launch_row_slab(TextureOps<false, true>{a, n}, a.n, active_dev != nullptr, as_stream(stream))) {
             WN_LAUNCH_CHECK("row_slab_points_kernel(texture)");
             return WN_OK;
         }
