@@ -25,6 +25,11 @@ KERNEL_OF = {  # substring of the dominant kernel's name per workload
 }
 
 
+# a second kernel of the same call whose traffic belongs to the call (texture_points: the plane-ordered pass that keeps or marks
+# every chunk before the row-slab kernel runs)
+COMPANION_OF = {"texture_points": "plane_sorted_points_kernel"}
+
+
 def summarize(tag, workloads):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     doc = {"tag": tag,
@@ -47,9 +52,12 @@ def summarize(tag, workloads):
                     entry["trace"] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                       "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3}
         counters = {}
+        companion = collections.defaultdict(list)
         for f in sorted(glob.glob(os.path.join(d, "pmc_*", "*", "*counter_collection.csv"))):
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
+                if wl in COMPANION_OF and COMPANION_OF[wl] in r["Kernel_Name"] and r["Counter_Name"] in ("WRITE_SIZE", "FETCH_SIZE"):
+                    companion[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 if key in r["Kernel_Name"]:
                     agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     for col in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Workgroup_Size", "Grid_Size"):
@@ -71,8 +79,14 @@ def summarize(tag, workloads):
             derived["l1_miss_share_(tcc_read_req/cache_accesses)"] = round(c.get("TCP_TCC_READ_REQ_sum", 0) / c["TCP_TOTAL_CACHE_ACCESSES_sum"], 3)
         if "WRITE_SIZE" in c and "FETCH_SIZE" in c:
             derived["hbm_bytes"] = c["WRITE_SIZE"] * 1024 + 2 * c["FETCH_SIZE"] * 1024
+            if companion.get("WRITE_SIZE") and companion.get("FETCH_SIZE"):
+                cw, cf = (sum(companion[k]) / len(companion[k]) for k in ("WRITE_SIZE", "FETCH_SIZE"))
+                entry["companion"] = {"kernel_match": COMPANION_OF[wl], "WRITE_SIZE": round(cw, 1), "FETCH_SIZE": round(cf, 1),
+                                      "hbm_bytes": cw * 1024 + 2 * cf * 1024}
+                derived["hbm_bytes_with_companion"] = derived["hbm_bytes"] + entry["companion"]["hbm_bytes"]
             traffic.append({"kernel": key, "workload": wl, "write_bytes": c["WRITE_SIZE"] * 1024,
-                            "fetch_bytes_corrected": 2 * c["FETCH_SIZE"] * 1024, "bytes_per_launch": derived["hbm_bytes"],
+                            "fetch_bytes_corrected": 2 * c["FETCH_SIZE"] * 1024,
+                            "bytes_per_launch": derived.get("hbm_bytes_with_companion", derived["hbm_bytes"]),
                             "source": f"profiles/{tag}_workloads.json (separate --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)"})
         if c.get("GRBM_GUI_ACTIVE") and entry.get("trace"):
             derived["effective_clock_GHz"] = round(c["GRBM_GUI_ACTIVE"] / 8 / (entry["trace"]["avg_us"] * 1e3), 3)

@@ -223,52 +223,58 @@ __global__ __launch_bounds__(256) void plane_sorted_points_kernel(const Ops ops)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t begin = (size_t)blockIdx.x * kSortChunk;
     const int count = (int)min((size_t)kSortChunk, ops.count - begin);
-    __shared__ unsigned s_rows[DEFER ? 128 : 1], s_top, s_near;
-    for (int b = tid; b < kSortBins; b += 256) hist[b] = 0;
-    if (tid == 0) {
-        s_changes = 0;
-        s_top = 0;
-        s_near = 0;
+    if constexpr (DEFER) {
+        // Is this chunk one for the row-slab kernel that follows on the stream -- hits scattered over an axis-aligned surface?
+        // The first wave looks at 32 pairs of neighbours spread over the chunk before anything else happens (one memory round
+        // trip, one barrier: 16,600 of the stand-in's 19,531 workgroups end here): at least half of the pairs on different
+        // planes, hardly any in neighbouring cells, three quarters of the 64 points on one middle y row.  Every other chunk
+        // stays: coherent ones, and the renderer's bounce-interleaved hits, which sort well (this kernel's 20 waves per CU beat
+        // the slab kernel's 16 on them).  Whole chunks only: every wave of the slab kernel has its mark.
+        __shared__ int s_defer;
+        if (count == kSortChunk) {
+            if (wave == 0) {
+                const size_t si = begin + (size_t)(lane >> 1) * (kSortChunk / 32) + (lane & 1);
+                const int kz = ops.mid_z(si), kx = ops.mid_x(si), ky = ops.mid_y(si);
+                const int pz = __shfl_up(kz, 1, 64), px = __shfl_up(kx, 1, 64);
+                const bool second = lane & 1;
+                const int changes = __popcll(__ballot(second && pz != kz));
+                const int near = __popcll(__ballot(second && abs(pz - kz) <= 1 && abs(px - kx) <= 1));
+                unsigned long long rest = ~0ull;
+                int top = 0;
+                for (int c = 0; c < 3 && rest; ++c) { // the most frequent row is among the first three distinct ones, or none is frequent
+                    const int r = __shfl(ky, __ffsll((long long)rest) - 1, 64);
+                    const unsigned long long same = __ballot(ky == r);
+                    top = max(top, (int)__popcll(same));
+                    rest &= ~same;
+                }
+                if (lane == 0) s_defer = changes >= 16 && near <= 3 && top >= 48;
+            }
+            __syncthreads();
+            if (s_defer) {
+                // (one mark per wave of that kernel, where the wave's own first store goes: its waves run through such chunks
+                // without a barrier, and a mark one wave has overwritten must not tell another that the chunk is done)
+                if (tid < kDeferMarks) ops.store(begin + kDeferMarkStride * tid, __uint_as_float(kDeferredBits));
+                return;
+            }
+        }
     }
-    if (DEFER && tid < 128) s_rows[tid] = 0;
+    for (int b = tid; b < kSortBins; b += 256) hist[b] = 0;
+    if (tid == 0) s_changes = 0;
     __syncthreads();
     // sample (the chunk's first 256 points): do neighbours of the stream change plane?  (A second test, "... and share
     // rows", would spare lists scattered in all three dimensions the 5 % the sorting passes cost them -- 25.4 -> 24.1 G
     // points/s -- but it also turns away curved surfaces, which gain: the stand-in's sphere hits, 1.19 -> 1.34 ms.)
     {
-        const size_t si = begin + min(tid, count - 1);
-        const int k = ops.mid_z(si);
+        const int k = ops.mid_z(begin + min(tid, count - 1));
         const int prev = __shfl_up(k, 1, 64);
         const unsigned long long diff = __ballot(lane != 0 && prev != k);
         if (lane == 0) atomicAdd(&s_changes, (unsigned)__popcll(diff));
-        if constexpr (DEFER) { // ... are neighbours at least in neighbouring cells?  which middle y rows?
-            const int kx = ops.mid_x(si), prevx = __shfl_up(kx, 1, 64);
-            const unsigned long long near = __ballot(lane != 0 && abs(prev - k) <= 1 && abs(prevx - kx) <= 1);
-            if (lane == 0) atomicAdd(&s_near, (unsigned)__popcll(near));
-            atomicAdd(&s_rows[ops.mid_y(si) & 127], 1u);
-        }
     }
     __syncthreads();
     if (s_changes < 128) { // coherent already: stream order, no sorting passes
         for (int i = tid; i < count; i += 256)
             if (ops.active(begin + i)) ops.store(begin + i, ops.eval(begin + i));
         return;
-    }
-    if constexpr (DEFER) {
-        // Incoherent.  Hits scattered over an axis-aligned surface -- hardly any neighbours of the stream in neighbouring
-        // cells, three quarters of the sample on one middle y row -- are what the row-slab kernel is for: it follows on the
-        // stream and takes the chunk.  This kernel keeps every other chunk (the renderer's bounce-interleaved hits sort well:
-        // its plane-ordered path at 20 waves per CU beats the slab kernel's 16 on them).
-        if (s_near * 10 <= 256 && count == kSortChunk) { // (whole chunks only: every wave of the slab kernel has its mark)
-            if (tid < 128) atomicMax(&s_top, s_rows[tid]);
-            __syncthreads();
-            if (s_top * 4 >= 256 * 3) {
-                // (one mark per wave of that kernel, where the wave's own first store goes: its waves run through such
-                // chunks without a barrier, and a mark one wave has overwritten must not tell another that the chunk is done)
-                if (tid < kDeferMarks) ops.store(begin + kDeferMarkStride * tid, __uint_as_float(kDeferredBits));
-                return;
-            }
-        }
     }
     // pass 1: bin and rank of every point (one LDS atomic each)
     unsigned short key[kSortPerThread], rank[kSortPerThread];
@@ -638,6 +644,9 @@ bool launch_row_slab(Ops ops, int n, bool masked, hipStream_t stream)
     if (!wn::ensure_dynamic_lds(fn, dev, kSlabLdsBytes)) return false; // the runtime refused the LDS opt-in
     const int grid = (int)std::min<size_t>(chunks, (size_t)wn::device_compute_units(dev));
     hipLaunchKernelGGL((plane_sorted_points_kernel<Ops, true>), dim3((unsigned)chunks), dim3(256), 0, stream, ops);
+#ifdef WN_TUNE_ENV
+    if (getenv("WN_ROW_SLAB_FIRST_ONLY")) return true; // experiment: the marks stay in the output
+#endif
     hipLaunchKernelGGL((row_slab_points_kernel<Ops>), dim3((unsigned)grid), dim3(kSlabThreads), kSlabLdsBytes, stream, ops, (int)chunks, 1);
     return true;
 }
