@@ -37,11 +37,12 @@ __device__ __forceinline__ float eval2d_exact(const float *coef, int n, int nmas
 // PADDED: `coef` is wn_tile::dev_padded (row stride n+2 with two wrap-around columns), so the
 // three x taps of every (y,z) row are adjacent and fetched with one 12-byte load; the values, the
 // arithmetic and its order are those of the linear layout.
-template <bool PADDED = false>
-__device__ __forceinline__ float eval3d_exact(const float *coef, int n, int nmask, float px,
-                                              float py, float pz)
+// POW2: the tile size is a power of two and the wrap a mask.  The general modulo behind a run-time test per index splits the
+// nine loads into basic blocks (a branch per wrap); eval3d_exact tests once and calls the form that has none.
+template <bool PADDED, bool POW2>
+__device__ __forceinline__ float eval3d_exact_impl(const float *coef, int n, int nmask, float px,
+                                                   float py, float pz)
 {
-    if (n == 0) return 0.0f; // :186-188
     int mx, my, mz;
     float wx[3], wy[3], wz[3];
     bspline(px, mx, wx[0], wx[1], wx[2]);
@@ -51,9 +52,9 @@ __device__ __forceinline__ float eval3d_exact(const float *coef, int n, int nmas
     int cx[3], cy[3], cz[3];
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
-        cx[f] = dmod(mx + f - 1, n, nmask);
-        cy[f] = dmod(my + f - 1, n, nmask) * stride;
-        cz[f] = dmod(mz + f - 1, n, nmask) * stride * n;
+        cx[f] = POW2 ? ((mx + f - 1) & nmask) : dmod(mx + f - 1, n, -1);
+        cy[f] = (POW2 ? ((my + f - 1) & nmask) : dmod(my + f - 1, n, -1)) * stride;
+        cz[f] = (POW2 ? ((mz + f - 1) & nmask) : dmod(mz + f - 1, n, -1)) * stride * n;
     }
     float result = 0.0f;
 #pragma unroll
@@ -74,6 +75,15 @@ __device__ __forceinline__ float eval3d_exact(const float *coef, int n, int nmas
             }
         }
     return result;
+}
+
+template <bool PADDED = false>
+__device__ __forceinline__ float eval3d_exact(const float *coef, int n, int nmask, float px,
+                                              float py, float pz)
+{
+    if (n == 0) return 0.0f; // :186-188
+    return nmask >= 0 ? eval3d_exact_impl<PADDED, true>(coef, n, nmask, px, py, pz)
+                      : eval3d_exact_impl<PADDED, false>(coef, n, nmask, px, py, pz);
 }
 
 // evaluate3D on the padded tile with two of its y rows held in LDS: `slab` = [z][2][n + 2], the rows (ry - 1) mod n and ry of
