@@ -80,10 +80,12 @@ int wn_comm_create(wn_comm **out, int world, int rank, const void *id_bytes)
         (void)hipGetLastError();
         return fail(WN_ERR_NO_DEVICE, "no HIP device: the sharded path has no CPU implementation");
     }
+    int device = 0;
+    SHARD_HIP(hipGetDevice(&device));
     wn_comm *c = new wn_comm();
     c->rank = rank;
     c->world = world;
-    SHARD_HIP(hipGetDevice(&c->device));
+    c->device = device;
     ncclUniqueId id;
     std::memcpy(&id, id_bytes, sizeof(id));
     const ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
